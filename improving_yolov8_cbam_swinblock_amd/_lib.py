@@ -1,0 +1,212 @@
+"""ctypes binding of libyolo_mi355.so (the C ABI declared in include/ymi.h).
+
+The library is the product: there is NO fallback.  If it cannot be loaded (not built, wrong arch)
+every op raises; nothing in this package computes on the CPU or through another backend.
+"""
+import ctypes
+import os
+import subprocess
+import threading
+from pathlib import Path
+
+import torch
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC_DIR = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libyolo_mi355.so"
+
+YMI_F32, YMI_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+_c_i64 = ctypes.c_int64
+_c_i32 = ctypes.c_int32
+_c_f32 = ctypes.c_float
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+
+
+class YmiTensor(ctypes.Structure):
+    _fields_ = [
+        ("data", _vp),
+        ("n", _c_i64),
+        ("h", _c_i64),
+        ("w", _c_i64),
+        ("c", _c_i64),
+        ("ld", _c_i64),
+        ("dtype", _c_i32),
+        ("_pad", _c_i32),
+    ]
+
+
+_TP = ctypes.POINTER(YmiTensor)
+
+# name -> (restype, argtypes).  Must list every function include/ymi.h declares (tests check it).
+_SIGNATURES = {
+    "ymi_version": (_c_i32, []),
+    "ymi_last_error": (ctypes.c_char_p, []),
+    "ymi_nchw_to_nhwc": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
+    "ymi_nhwc_to_nchw": (_c_i32, [_TP, _vp, _vp]),
+    "ymi_copy": (_c_i32, [_TP, _TP, _vp]),
+    "ymi_upsample2x": (_c_i32, [_TP, _TP, _vp]),
+    "ymi_upsample2x_bwd": (_c_i32, [_TP, _TP, _vp]),
+    "ymi_add_inplace": (_c_i32, [_TP, _TP, _vp]),
+    "ymi_pack_conv_weight_fwd": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _vp, _vp]),
+    "ymi_pack_conv_weight_dgrad": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _vp, _vp]),
+    "ymi_pack_conv_weight_dgrad_ex": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _vp, _vp]),
+    "ymi_conv_dgrad_pack_elems": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "ymi_pack_matrix": (_c_i32, [_vp, _c_i64, _c_i64, _c_i32, _c_i32, _vp, _vp]),
+    "ymi_conv2d_fwd": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _c_i32, _TP, _TP, _vp, ctypes.POINTER(_c_i64), _vp]),
+    "ymi_conv2d_stat_blocks": (_c_i64, [_c_i64, _c_i64]),
+    "ymi_bn_finalize": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _vp, _vp, _vp, _vp, _vp]),
+    "ymi_scale_shift_act": (_c_i32, [_TP, _vp, _vp, _c_i32, _TP, _TP, _vp]),
+    "ymi_conv2d_bn_silu_fwd": (
+        _c_i32,
+        [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _TP, _vp, _vp, _vp, _sz, _vp],
+    ),
+    "ymi_bn_act_bwd": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
+    "ymi_conv2d_bwd_data": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
+    "ymi_conv2d_bwd_weight": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp]),
+    "ymi_conv2d_bwd_weight_workspace": (_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "ymi_sppf_pool3_fwd": (_c_i32, [_TP, _c_i64, _TP, _TP, _TP, _vp]),
+    "ymi_sppf_pool3_bwd": (_c_i32, [_TP, _TP, _TP, _c_i64, _TP, _TP, _TP, _TP, _vp]),
+    "ymi_cbam_fwd": (_c_i32, [_TP, _vp, _vp, _c_i64, _vp, _c_i64, _TP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ymi_cbam_bwd": (_c_i32, [_TP, _TP, _vp, _vp, _c_i64, _vp, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _TP, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "ymi_cbam_bwd_workspace": (_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "ymi_window_partition_index": (_c_i32, [_c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp]),
+    "ymi_window_partition": (_c_i32, [_TP, _c_i64, _TP, _vp]),
+    "ymi_window_reverse": (_c_i32, [_TP, _c_i64, _TP, _vp]),
+    "ymi_layernorm_fwd": (_c_i32, [_TP, _c_i64, _vp, _vp, _c_f32, _TP, _vp, _vp, _vp]),
+    "ymi_layernorm_bwd": (_c_i32, [_TP, _c_i64, _TP, _vp, _vp, _vp, _TP, _c_i32, _vp, _vp, _vp, _sz, _vp]),
+    "ymi_window_attention_fwd": (_c_i32, [_TP, _c_i64, _c_i64, _TP, _vp, _vp]),
+    "ymi_window_attention_bwd": (_c_i32, [_TP, _TP, _TP, _vp, _c_i64, _c_i64, _TP, _vp]),
+    "ymi_colsum": (_c_i32, [_TP, _vp, _vp, _sz, _vp]),
+    "ymi_gelu_bwd": (_c_i32, [_TP, _TP, _TP, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+def build(verbose=False):
+    """Compile csrc/*.hip for gfx950 into libyolo_mi355.so (hipcc cross-compiles without a GPU)."""
+    jobs = str(min(8, os.cpu_count() or 1))
+    proc = subprocess.run(["make", "-C", str(CSRC_DIR), "-j", jobs], capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"building libyolo_mi355.so failed:\n{proc.stdout[-4000:]}\n{proc.stderr[-4000:]}")
+    if verbose:
+        print(proc.stdout[-2000:])
+    return LIB_PATH
+
+
+def lib():
+    """The loaded library (loads on first use). Raises if it is missing: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not LIB_PATH.exists():
+                    raise RuntimeError(
+                        f"{LIB_PATH} is missing: build it with improving_yolov8_cbam_swinblock_amd._lib.build() "
+                        "(make -C csrc); this package has no CPU or PyTorch fallback"
+                    )
+                handle = ctypes.CDLL(str(LIB_PATH))
+                missing = []
+                for name, (res, args) in _SIGNATURES.items():
+                    try:
+                        fn = getattr(handle, name)
+                    except AttributeError:
+                        missing.append(name)
+                        continue
+                    fn.restype = res
+                    fn.argtypes = args
+                if missing:
+                    raise RuntimeError(f"{LIB_PATH} is stale, missing symbols {missing}: rebuild with make -C csrc")
+                _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return list(_SIGNATURES)
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().ymi_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"libyolo_mi355 {what} failed ({rc}): {msg}")
+
+
+def ymi_dtype(dt):
+    if dt == torch.float32:
+        return YMI_F32
+    if dt == torch.bfloat16:
+        return YMI_BF16
+    raise TypeError(f"libyolo_mi355 computes in float32 or bfloat16, got {dt}")
+
+
+def chunk_elems(dt):
+    """elements per 16-byte chunk: the channel granularity of the implicit-GEMM operand loader."""
+    return 8 if dt == torch.bfloat16 else 4
+
+
+def is_nhwc(t):
+    """logical [N,C,H,W] tensor whose memory is dense NHWC with pixel stride ld >= C."""
+    if t.dim() != 4:
+        return False
+    n, c, h, w = t.shape
+    sn, sc, sh, sw = t.stride()
+    if c > 1 and sc != 1:
+        return False
+    ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+    if w > 1 and h > 1 and sh != w * ld:
+        return False
+    if (h > 1 or w > 1) and n > 1 and sn != h * w * ld:
+        return False
+    return ld >= c
+
+
+def as_ymi(t):
+    """torch tensor -> YmiTensor.  4-D: logical NCHW with NHWC memory; 2-D: [rows, C] token matrix."""
+    if not t.is_cuda:
+        raise RuntimeError("libyolo_mi355 kernels need tensors on the MI355X (cuda) device; there is no CPU path")
+    if t.dim() == 4:
+        if not is_nhwc(t):
+            raise RuntimeError(f"expected NHWC memory for a logical NCHW tensor, got shape {tuple(t.shape)} strides {t.stride()}")
+        n, c, h, w = t.shape
+        sn, sc, sh, sw = t.stride()
+        ld = sw if w > 1 else (sh if h > 1 else (sn if n > 1 else c))
+        return YmiTensor(t.data_ptr(), n, h, w, c, ld, ymi_dtype(t.dtype), 0)
+    if t.dim() == 2:
+        rows, c = t.shape
+        if c > 1 and t.stride(1) != 1:
+            raise RuntimeError("token matrix must have unit channel stride")
+        ld = t.stride(0) if rows > 1 else c
+        return YmiTensor(t.data_ptr(), 1, 1, rows, c, ld, ymi_dtype(t.dtype), 0)
+    raise RuntimeError(f"unsupported tensor rank {t.dim()}")
+
+
+def stream_ptr():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def empty_nhwc(n, c, h, w, dtype, device, ld=None):
+    """uninitialised logical [N,C,H,W] tensor in NHWC memory (optionally with a wider pixel stride)."""
+    ld = c if ld is None else ld
+    buf = torch.empty((n, h, w, ld), dtype=dtype, device=device)
+    return buf.permute(0, 3, 1, 2)[:, :c]
+
+
+_workspaces = {}
+
+
+def workspace(nbytes, device, tag="default"):
+    """grow-only scratch buffer per (device, stream, tag); contents are undefined between calls."""
+    key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
+    buf = _workspaces.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = buf
+    return buf

@@ -1,0 +1,134 @@
+// Shared device/host helpers for libyolo_mi355.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ymi.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define YMI_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void ymi_set_error(const char* fmt, ...);
+#define YMI_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            ymi_set_error(__VA_ARGS__);   \
+            return YMI_EINVAL;            \
+        }                                 \
+    } while (0)
+#define YMI_CHECK_LAUNCH(what)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            ymi_set_error("%s: launch failed: %s", what, hipGetErrorString(e_)); \
+            return YMI_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline bool ymi_tensor_ok(const ymi_tensor* t) {
+    return t && t->data && t->n > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c && (t->dtype == YMI_F32 || t->dtype == YMI_BF16);
+}
+static inline int64_t ymi_pixels(const ymi_tensor* t) { return t->n * t->h * t->w; }
+static inline size_t ymi_esize(int dtype) { return dtype == YMI_BF16 ? 2 : 4; }
+static inline bool ymi_same_shape(const ymi_tensor* a, const ymi_tensor* b) {
+    return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c;
+}
+// a 16-byte block of zeros in device memory (source of out-of-bounds im2col taps)
+const void* ymi_zero_page();
+
+// ---- element access helpers (device) ----------------------------------------------------------
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int CH = 4;  // elements per 16-byte chunk
+    static constexpr int DT = YMI_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int CH = 8;
+    static constexpr int DT = YMI_BF16;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+// load / store a group of G consecutive elements as floats (vector access when aligned by construction)
+template <typename T, int G> struct Pack;
+template <> struct Pack<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p) = t;
+    }
+};
+template <> struct Pack<bf16_t, 4> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+        bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+        bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(p) = t;
+    }
+};
+template <> struct Pack<bf16_t, 8> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+        *reinterpret_cast<bf16x8*>(p) = t;
+    }
+};
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float c = 0.39894228040143267794f;  // 1/sqrt(2 pi)
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * c * __expf(-0.5f * x * x);
+}
+template <int ACT> __device__ __forceinline__ float apply_act(float x) {
+    if (ACT == YMI_ACT_SILU) return silu_f(x);
+    if (ACT == YMI_ACT_GELU) return gelu_f(x);
+    return x;
+}
+__device__ __forceinline__ float apply_act_rt(float x, int act) {
+    return act == YMI_ACT_SILU ? silu_f(x) : act == YMI_ACT_GELU ? gelu_f(x) : x;
+}
+__device__ __forceinline__ float act_grad_rt(float x, int act) {
+    return act == YMI_ACT_SILU ? silu_grad_f(x) : act == YMI_ACT_GELU ? gelu_grad_f(x) : 1.0f;
+}
+
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

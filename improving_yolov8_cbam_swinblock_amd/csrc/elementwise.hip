@@ -1,0 +1,392 @@
+// Memory-bound helpers: layout changes, casts, weight packing, BatchNorm finalize / affine+activation.
+// All are grid-stride kernels over 4-element groups (8 B bf16 / 16 B f32 per lane access); tensors
+// whose ld or base is not 4-element aligned take a scalar path.
+#include "common.h"
+
+static inline dim3 ew_grid(int64_t work) {
+    int64_t b = (work + 255) / 256;
+    if (b > 256 * 16) b = 256 * 16;  // 16 workgroups per CU, grid-stride the rest
+    if (b < 1) b = 1;
+    return dim3((unsigned)b);
+}
+static inline bool vec4_ok(const ymi_tensor* t) {
+    return t->c % 4 == 0 && t->ld % 4 == 0 && ((uintptr_t)t->data % (4 * ymi_esize(t->dtype))) == 0;
+}
+
+struct TV {  // device view of a ymi_tensor
+    void* p;
+    int64_t ld;
+    int n, h, w, c;
+};
+static inline TV tv(const ymi_tensor* t) { return TV{t->data, t->ld, (int)t->n, (int)t->h, (int)t->w, (int)t->c}; }
+
+// ---------------------------------------------------------------------------------- NCHW <-> NHWC
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int64_t HW, int64_t NP, TV d) {
+    // one thread per (pixel, 4-channel group); reads are coalesced over pixels for each channel
+    const int groups = d.c / 4;
+    const int64_t total = NP * groups;
+    T* dst = reinterpret_cast<T*>(d.p);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t p = i % NP;  // pixel fastest -> coalesced source reads
+        const int g = (int)(i / NP);
+        const int64_t n = p / HW, hw = p - n * HW;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = g * 4 + r;
+            v[r] = c < C ? src[(n * C + c) * HW + hw] : 0.0f;
+        }
+        Pack<T, 4>::store(dst + p * d.ld + g * 4, v);
+    }
+}
+
+extern "C" int ymi_nchw_to_nhwc(const float* src, int64_t n, int64_t c, int64_t h, int64_t w, const ymi_tensor* dst, void* stream) {
+    YMI_CHECK_ARG(src && ymi_tensor_ok(dst), "nchw_to_nhwc: bad tensor");
+    YMI_CHECK_ARG(dst->n == n && dst->h == h && dst->w == w && dst->c >= c, "nchw_to_nhwc: shape");
+    YMI_CHECK_ARG(vec4_ok(dst), "nchw_to_nhwc: destination must be 4-channel aligned");
+    const int64_t np = n * h * w, total = np * (dst->c / 4);
+    if (dst->dtype == YMI_BF16)
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, src, (int)c, h * w, np, tv(dst));
+    else
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, src, (int)c, h * w, np, tv(dst));
+    YMI_CHECK_LAUNCH("nchw_to_nhwc");
+    return YMI_OK;
+}
+
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(TV s, float* __restrict__ dst, int64_t HW, int64_t total) {
+    const T* src = reinterpret_cast<const T*>(s.p);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t hw = i % HW;
+        const int64_t nc = i / HW;
+        const int c = (int)(nc % s.c);
+        const int64_t n = nc / s.c;
+        dst[i] = to_f32(src[(n * HW + hw) * s.ld + c]);
+    }
+}
+
+extern "C" int ymi_nhwc_to_nchw(const ymi_tensor* src, float* dst, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(src) && dst, "nhwc_to_nchw: bad tensor");
+    const int64_t hw = src->h * src->w, total = src->n * src->c * hw;
+    if (src->dtype == YMI_BF16)
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, tv(src), dst, hw, total);
+    else
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, tv(src), dst, hw, total);
+    YMI_CHECK_LAUNCH("nhwc_to_nchw");
+    return YMI_OK;
+}
+
+// ------------------------------------------------------------------- copy / upsample / accumulate
+// MODE 0: dst = src ; 1: dst(2h+i,2w+j) = src(h,w) ; 2: dst(h,w) = sum src(2h+i,2w+j) ; 3: dst += src
+template <typename TS, typename TD, int MODE, bool VEC>
+__global__ void move_kernel(TV s, TV d) {
+    constexpr int G = VEC ? 4 : 1;
+    const int groups = d.c / G;
+    const int64_t total = (int64_t)d.n * d.h * d.w * groups;
+    const TS* src = reinterpret_cast<const TS*>(s.p);
+    TD* dst = reinterpret_cast<TD*>(d.p);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const int64_t p = i / groups;
+        const int w = (int)(p % d.w);
+        const int64_t t = p / d.w;
+        const int h = (int)(t % d.h);
+        const int n = (int)(t / d.h);
+        float v[G];
+        auto ld = [&](int64_t sp, float (&o)[G]) {
+            if constexpr (VEC) Pack<TS, 4>::load(src + sp * s.ld + g * 4, o);
+            else o[0] = to_f32(src[sp * s.ld + g]);
+        };
+        if (MODE == 0 || MODE == 3) {
+            ld(p, v);
+        } else if (MODE == 1) {
+            ld(((int64_t)n * s.h + (h >> 1)) * s.w + (w >> 1), v);
+        } else {
+            float a[G], b[G], c2[G], e[G];
+            const int64_t base = ((int64_t)n * s.h + 2 * h) * s.w + 2 * w;
+            ld(base, a); ld(base + 1, b); ld(base + s.w, c2); ld(base + s.w + 1, e);
+#pragma unroll
+            for (int r = 0; r < G; ++r) v[r] = (a[r] + b[r]) + (c2[r] + e[r]);
+        }
+        if (MODE == 3) {
+            float o[G];
+            if constexpr (VEC) Pack<TD, 4>::load(dst + p * d.ld + g * 4, o);
+            else o[0] = to_f32(dst[p * d.ld + g]);
+#pragma unroll
+            for (int r = 0; r < G; ++r) v[r] += o[r];
+        }
+        if constexpr (VEC) Pack<TD, 4>::store(dst + p * d.ld + g * 4, v);
+        else dst[p * d.ld + g] = from_f32<TD>(v[0]);
+    }
+}
+
+template <int MODE>
+static int launch_move(const ymi_tensor* src, const ymi_tensor* dst, const char* what, hipStream_t stream) {
+    const bool vec = vec4_ok(src) && vec4_ok(dst);
+    const int64_t total = ymi_pixels(dst) * (vec ? dst->c / 4 : dst->c);
+    dim3 g = ew_grid(total), b(256);
+#define YMI_MV(TS, TD)                                                                              \
+    do {                                                                                            \
+        if (vec) hipLaunchKernelGGL((move_kernel<TS, TD, MODE, true>), g, b, 0, stream, tv(src), tv(dst));  \
+        else hipLaunchKernelGGL((move_kernel<TS, TD, MODE, false>), g, b, 0, stream, tv(src), tv(dst));     \
+    } while (0)
+    if (src->dtype == YMI_BF16 && dst->dtype == YMI_BF16) YMI_MV(bf16_t, bf16_t);
+    else if (src->dtype == YMI_F32 && dst->dtype == YMI_F32) YMI_MV(float, float);
+    else if (src->dtype == YMI_F32 && dst->dtype == YMI_BF16) YMI_MV(float, bf16_t);
+    else YMI_MV(bf16_t, float);
+#undef YMI_MV
+    YMI_CHECK_LAUNCH(what);
+    return YMI_OK;
+}
+
+extern "C" int ymi_copy(const ymi_tensor* src, const ymi_tensor* dst, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(src) && ymi_tensor_ok(dst) && ymi_same_shape(src, dst), "copy: shapes");
+    return launch_move<0>(src, dst, "copy", (hipStream_t)stream);
+}
+extern "C" int ymi_upsample2x(const ymi_tensor* src, const ymi_tensor* dst, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(src) && ymi_tensor_ok(dst), "upsample2x: bad tensor");
+    YMI_CHECK_ARG(dst->n == src->n && dst->h == 2 * src->h && dst->w == 2 * src->w && dst->c == src->c, "upsample2x: shapes");
+    return launch_move<1>(src, dst, "upsample2x", (hipStream_t)stream);
+}
+extern "C" int ymi_upsample2x_bwd(const ymi_tensor* src, const ymi_tensor* dst, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(src) && ymi_tensor_ok(dst), "upsample2x_bwd: bad tensor");
+    YMI_CHECK_ARG(dst->n == src->n && src->h == 2 * dst->h && src->w == 2 * dst->w && dst->c == src->c, "upsample2x_bwd: shapes");
+    return launch_move<2>(src, dst, "upsample2x_bwd", (hipStream_t)stream);
+}
+extern "C" int ymi_add_inplace(const ymi_tensor* src, const ymi_tensor* dst, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(src) && ymi_tensor_ok(dst) && ymi_same_shape(src, dst), "add_inplace: shapes");
+    return launch_move<3>(src, dst, "add_inplace", (hipStream_t)stream);
+}
+
+// --------------------------------------------------------------------------------- weight packing
+template <typename T>
+__global__ void pack_fwd_kernel(const float* __restrict__ w, int O, int I, int KH, int KW, int IP, T* __restrict__ dst) {
+    // dst[o][kh][kw][ip]  <-  w[o][i][kh][kw]
+    const int64_t total = (int64_t)O * KH * KW * IP;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ip = (int)(idx % IP);
+        int64_t t = idx / IP;
+        const int kw = (int)(t % KW); t /= KW;
+        const int kh = (int)(t % KH);
+        const int o = (int)(t / KH);
+        const float v = ip < I ? w[(((int64_t)o * I + ip) * KH + kh) * KW + kw] : 0.0f;
+        dst[idx] = from_f32<T>(v);
+    }
+}
+
+extern "C" int ymi_pack_conv_weight_fwd(const float* w, int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t ipad, int32_t dtype,
+                                        void* dst, void* stream) {
+    YMI_CHECK_ARG(w && dst && ipad >= i && o > 0 && i > 0, "pack_conv_weight_fwd: args");
+    const int64_t total = o * kh * kw * ipad;
+    if (dtype == YMI_BF16)
+        hipLaunchKernelGGL(pack_fwd_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, (int)o, (int)i, (int)kh, (int)kw, (int)ipad, (bf16_t*)dst);
+    else
+        hipLaunchKernelGGL(pack_fwd_kernel<float>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, (int)o, (int)i, (int)kh, (int)kw, (int)ipad, (float*)dst);
+    YMI_CHECK_LAUNCH("pack_conv_weight_fwd");
+    return YMI_OK;
+}
+
+struct DgradPack {
+    int ntaps;          // taps of this class
+    int kh[9], kw[9];   // original kernel coordinates of each tap
+    int64_t off;        // element offset of the class block
+};
+template <typename T>
+__global__ void pack_dgrad_kernel(const float* __restrict__ w, int O, int OP, int I, int KH, int KW, DgradPack d, T* __restrict__ dst) {
+    // class block: dst[i][t][op]  <-  w[o][i][kh_t][kw_t]
+    const int64_t total = (int64_t)I * d.ntaps * OP;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int o = (int)(idx % OP);
+        int64_t t = idx / OP;
+        const int tp = (int)(t % d.ntaps);
+        const int i = (int)(t / d.ntaps);
+        const float v = o < O ? w[(((int64_t)o * I + i) * KH + d.kh[tp]) * KW + d.kw[tp]] : 0.0f;
+        dst[d.off + idx] = from_f32<T>(v);
+    }
+}
+
+// `o` is the PADDED channel count of dy (multiple of 8 bf16 / 4 f32); o_real rows exist in w.
+extern "C" int ymi_pack_conv_weight_dgrad_ex(const float* w, int64_t o_real, int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t stride,
+                                             int32_t dtype, void* dst, void* stream) {
+    YMI_CHECK_ARG(w && dst && o >= o_real && (stride == 1 || stride == 2), "pack_conv_weight_dgrad: args");
+    const int pad = (int)kh / 2;
+    const int nclass = stride == 1 ? 1 : 4;
+    int64_t off = 0;
+    for (int cls = 0; cls < nclass; ++cls) {
+        const int ph = stride == 1 ? 0 : cls / 2, pw = stride == 1 ? 0 : cls % 2;
+        DgradPack d{};
+        for (int a = 0; a < kh; ++a)
+            for (int b = 0; b < kw; ++b) {
+                const int nh = ph + pad - a, nw = pw + pad - b;
+                if (nh % (int)stride != 0 || nw % (int)stride != 0) continue;
+                d.kh[d.ntaps] = a; d.kw[d.ntaps] = b; ++d.ntaps;
+            }
+        d.off = off;
+        const int64_t total = i * d.ntaps * o;
+        if (total > 0) {
+            if (dtype == YMI_BF16)
+                hipLaunchKernelGGL(pack_dgrad_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, (int)o_real, (int)o, (int)i, (int)kh, (int)kw, d, (bf16_t*)dst);
+            else
+                hipLaunchKernelGGL(pack_dgrad_kernel<float>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, w, (int)o_real, (int)o, (int)i, (int)kh, (int)kw, d, (float*)dst);
+        }
+        off += total;
+    }
+    YMI_CHECK_LAUNCH("pack_conv_weight_dgrad");
+    return YMI_OK;
+}
+extern "C" int ymi_pack_conv_weight_dgrad(const float* w, int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t stride, int32_t dtype,
+                                          void* dst, void* stream) {
+    return ymi_pack_conv_weight_dgrad_ex(w, o, o, i, kh, kw, stride, dtype, dst, stream);
+}
+
+template <typename T>
+__global__ void pack_matrix_kernel(const float* __restrict__ src, int R, int C, int transpose, T* __restrict__ dst) {
+    const int64_t total = (int64_t)R * C;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        if (!transpose) {
+            dst[idx] = from_f32<T>(src[idx]);
+        } else {  // dst[c][r] = src[r][c]; idx walks dst
+            const int r = (int)(idx % R);
+            const int c = (int)(idx / R);
+            dst[idx] = from_f32<T>(src[(int64_t)r * C + c]);
+        }
+    }
+}
+extern "C" int ymi_pack_matrix(const float* src, int64_t rows, int64_t cols, int32_t transpose, int32_t dtype, void* dst, void* stream) {
+    YMI_CHECK_ARG(src && dst && rows > 0 && cols > 0, "pack_matrix: args");
+    const int64_t total = rows * cols;
+    if (dtype == YMI_BF16)
+        hipLaunchKernelGGL(pack_matrix_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, src, (int)rows, (int)cols, transpose, (bf16_t*)dst);
+    else
+        hipLaunchKernelGGL(pack_matrix_kernel<float>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, src, (int)rows, (int)cols, transpose, (float*)dst);
+    YMI_CHECK_LAUNCH("pack_matrix");
+    return YMI_OK;
+}
+
+// ------------------------------------------------------------------------------ BatchNorm pieces
+// One thread column per channel, 4 row-slices per block; sums in double so that the cross-block
+// reduction adds nothing to the error of the per-block f32 partials.
+__global__ void bn_finalize_kernel(const float* __restrict__ part, int blocks, double count, int C, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
+                                   float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
+                                   float* __restrict__ sinv) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C) {
+        for (int b = slice; b < blocks; b += 4) {
+            s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
+            s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
+        }
+    }
+    red[0][slice][cl] = s1;
+    red[1][slice][cl] = s2;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+        s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        const double mean = s1 / count;
+        double var = s2 / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float inv = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+        const float sc = g * inv;
+        scale[c] = sc;
+        shift[c] = b - (float)mean * sc;
+        if (smean) smean[c] = (float)mean;
+        if (sinv) sinv[c] = inv;
+        if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+        if (rvar) {
+            const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+        }
+    }
+}
+
+extern "C" int ymi_bn_finalize(const float* part, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
+                               float* rmean, float* rvar, float momentum, float eps, float* scale, float* shift, float* smean,
+                               float* sinv, void* stream) {
+    YMI_CHECK_ARG(part && scale && shift && blocks > 0 && count > 0 && c > 0, "bn_finalize: args");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(256), 0, (hipStream_t)stream, part, (int)blocks,
+                       (double)count, (int)c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv);
+    YMI_CHECK_LAUNCH("bn_finalize");
+    return YMI_OK;
+}
+
+template <typename T, bool VEC>
+__global__ void scale_shift_act_kernel(TV x, const float* __restrict__ scale, const float* __restrict__ shift, int act, TV res, TV o) {
+    constexpr int G = VEC ? 4 : 1;
+    const int groups = x.c / G;
+    const int64_t total = (int64_t)x.n * x.h * x.w * groups;
+    const T* xp = reinterpret_cast<const T*>(x.p);
+    const T* rp = reinterpret_cast<const T*>(res.p);
+    T* op = reinterpret_cast<T*>(o.p);
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const int64_t p = i / groups;
+        float v[G];
+        if constexpr (VEC) Pack<T, 4>::load(xp + p * x.ld + g * 4, v);
+        else v[0] = to_f32(xp[p * x.ld + g]);
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+            const int c = g * G + r;
+            const float s = scale ? scale[c] : 1.0f, b = shift ? shift[c] : 0.0f;
+            v[r] = apply_act_rt(v[r] * s + b, act);
+        }
+        if (rp) {
+            float rr[G];
+            if constexpr (VEC) Pack<T, 4>::load(rp + p * res.ld + g * 4, rr);
+            else rr[0] = to_f32(rp[p * res.ld + g]);
+#pragma unroll
+            for (int r = 0; r < G; ++r) v[r] += rr[r];
+        }
+        if constexpr (VEC) Pack<T, 4>::store(op + p * o.ld + g * 4, v);
+        else op[p * o.ld + g] = from_f32<T>(v[0]);
+    }
+}
+
+extern "C" int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, const float* shift, int32_t act, const ymi_tensor* residual,
+                                   const ymi_tensor* out, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(raw) && ymi_tensor_ok(out) && ymi_same_shape(raw, out) && raw->dtype == out->dtype, "scale_shift_act: shapes");
+    if (residual) YMI_CHECK_ARG(ymi_tensor_ok(residual) && ymi_same_shape(residual, out) && residual->dtype == out->dtype, "scale_shift_act: residual");
+    const bool vec = vec4_ok(raw) && vec4_ok(out) && (!residual || vec4_ok(residual));
+    const int64_t total = ymi_pixels(raw) * (vec ? raw->c / 4 : raw->c);
+    TV r = residual ? tv(residual) : TV{nullptr, 0, 0, 0, 0, 0};
+    dim3 g = ew_grid(total), b(256);
+    hipStream_t s = (hipStream_t)stream;
+    if (raw->dtype == YMI_BF16) {
+        if (vec) hipLaunchKernelGGL((scale_shift_act_kernel<bf16_t, true>), g, b, 0, s, tv(raw), scale, shift, act, r, tv(out));
+        else hipLaunchKernelGGL((scale_shift_act_kernel<bf16_t, false>), g, b, 0, s, tv(raw), scale, shift, act, r, tv(out));
+    } else {
+        if (vec) hipLaunchKernelGGL((scale_shift_act_kernel<float, true>), g, b, 0, s, tv(raw), scale, shift, act, r, tv(out));
+        else hipLaunchKernelGGL((scale_shift_act_kernel<float, false>), g, b, 0, s, tv(raw), scale, shift, act, r, tv(out));
+    }
+    YMI_CHECK_LAUNCH("scale_shift_act");
+    return YMI_OK;
+}
+
+// Conv + train-mode BN + activation: three launches, one C call.
+extern "C" int ymi_conv2d_bn_silu_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                                      const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                      float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
+                                      float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(raw) && ymi_tensor_ok(out) && workspace, "conv2d_bn_silu_fwd: bad tensor");
+    const int64_t m = ymi_pixels(raw);
+    const int64_t maxblk = ymi_conv2d_stat_blocks(m, cout);
+    const size_t need = (size_t)(maxblk * 2 * cout + 2 * cout) * sizeof(float);
+    if (workspace_bytes < need) {
+        ymi_set_error("conv2d_bn_silu_fwd: workspace %zu < %zu bytes", workspace_bytes, need);
+        return YMI_EWORKSPACE;
+    }
+    float* scale = reinterpret_cast<float*>(workspace);
+    float* shift = scale + cout;
+    float* part = shift + cout;
+    int64_t blocks = 0;
+    int rc = ymi_conv2d_fwd(x, w_packed, cout, kh, kw, stride, nullptr, nullptr, YMI_ACT_NONE, nullptr, raw, part, &blocks, stream);
+    if (rc) return rc;
+    rc = ymi_bn_finalize(part, blocks, m, cout, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, stream);
+    if (rc) return rc;
+    return ymi_scale_shift_act(raw, scale, shift, act, residual, out, stream);
+}

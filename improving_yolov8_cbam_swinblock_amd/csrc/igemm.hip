@@ -1,0 +1,444 @@
+// Implicit-GEMM NHWC convolution on MFMA for gfx950.
+//
+//   Y[pixel m][channel n] = sum_k A[m][k] * Wp[n][k],   k = (tap, ci)
+//
+// A is the im2col view of the NHWC input, never materialised: row m is an output pixel, the K axis
+// walks a TAP TABLE (dh,dw per tap) outer and the input channels inner, so every 16-byte chunk of a
+// row is one contiguous piece of one input pixel (or zeros when the tap falls outside the image).
+// Forward convolution, stride-1 data-gradient and the four output-parity classes of a stride-2
+// data-gradient are all the same kernel with different tap tables / output strides; with one tap it
+// is a plain token GEMM (Swin linears).
+//
+// MI355X mapping
+//  * 256-thread workgroups (4 waves), block tile BM pixels x BN channels, K step = 64 bytes per row
+//    (32 bf16 / 16 f32): both operand tiles are [rows][64 B] images in LDS.
+//  * tiles are filled with global_load_lds_dwordx4 (16 B per lane straight into LDS, no VGPR
+//    staging).  The LDS destination is lane-linear, so the bank-conflict swizzle
+//    chunk' = chunk ^ ((row>>2)&3) is applied to the per-lane SOURCE address and again on the read.
+//  * MFMA operands are swapped (A = weights, B = activations): the 16x16 accumulator then holds 4
+//    consecutive CHANNELS of one pixel per lane, which is a contiguous 8/16-byte NHWC store.
+//  * bf16: v_mfma_f32_16x16x32_bf16; f32 parity mode: v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).
+//  * epilogue variants: (a) raw output + deterministic per-block BatchNorm partial sums
+//    (no atomics), (b) scale/bias/activation/residual.
+#include "common.h"
+
+struct IgemmArgs {
+    const void* x;
+    const void* w;
+    void* y;
+    const void* res;
+    const float* scale;
+    const float* bias;
+    float* partials;
+    const void* zero;
+    int64_t ldx, ldy, ldres, ktot;
+    int M, H, W, Ho, Wo, Hy, Wy;
+    int s_in, s_out, oh_off, ow_off;
+    int Cout, cpt, ntaps, KC;
+    uint64_t tap_dh, tap_dw;
+    int act, vec_store;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    // one K step (64 B per row) = one 16x16x32 MFMA per tile pair
+    template <int TM, int TN>
+    static __device__ __forceinline__ void step(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM]) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int sw = ((l15 >> 2) & 3);
+        const int coff = ((l4 ^ sw) << 4);
+        bf16x8 wf[TN], xf[TM];
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const bf16x8*>(Bs + (b_row0 + tn * 16 + l15) * 64 + coff);
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const bf16x8*>(As + (a_row0 + tm * 16 + l15) * 64 + coff);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    // one K step = 16 floats per row = four 16x16x4 f32 MFMAs per tile pair
+    template <int TM, int TN>
+    static __device__ __forceinline__ void step(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM]) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int sw = ((l15 >> 2) & 3);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int coff = ((ks ^ sw) << 4) + (l4 << 2);
+            float wf[TN], xf[TM];
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const float*>(Bs + (b_row0 + tn * 16 + l15) * 64 + coff);
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const float*>(As + (a_row0 + tm * 16 + l15) * 64 + coff);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+        }
+    }
+};
+
+template <typename T, int BM, int BN, int WM, int WN, bool STATS>
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+    constexpr int CH = ElemTraits<T>::CH;
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256;
+    constexpr int STAGE = (BM + BN) * 64;
+    static_assert(WM * WN == 4, "4 waves");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+
+    // ---- per-thread load descriptors -----------------------------------------------------------
+    const int c = (tid & 3) ^ ((tid >> 4) & 3);  // source chunk (0..3) of the K step this thread fetches
+    int tap = c / a.cpt;
+    int cic = c - tap * a.cpt;
+    const int adv_tap = 4 / a.cpt, adv_c = 4 - adv_tap * a.cpt;  // one K step = 4 chunks further along (tap, ci)
+    int a_nH[NA], a_h[NA], a_w[NA];
+    bool a_ok[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int r = (tid >> 2) + 64 * i;
+        const int m = m0 + r;
+        a_ok[i] = (m < a.M) && (r < BM);
+        const int mm = a_ok[i] ? m : 0;
+        const int wo = mm % a.Wo;
+        const int t = mm / a.Wo;
+        const int ho = t % a.Ho;
+        const int n = t / a.Ho;
+        a_nH[i] = n * a.H;
+        a_h[i] = ho * a.s_in;
+        a_w[i] = wo * a.s_in;
+    }
+    const T* b_ptr[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int rn = (tid >> 2) + 64 * j;
+        const int n = n0 + rn;
+        b_ok[j] = (n < a.Cout) && (rn < BN);
+        b_ptr[j] = wg + (int64_t)(b_ok[j] ? n : 0) * a.ktot;
+    }
+
+    auto issue = [&](int s) {
+        char* As = smem + s * STAGE;
+        char* Bs = As + BM * 64;
+        const bool kvalid = tap < a.ntaps;
+        const int dh = (int)((a.tap_dh >> (4 * (tap & 15))) & 15) - 8;
+        const int dw = (int)((a.tap_dw >> (4 * (tap & 15))) & 15) - 8;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            if ((wave * 16 + 64 * i) < BM) {  // wave-uniform
+                const int hi = a_h[i] + dh, wi = a_w[i] + dw;
+                const bool ok = a_ok[i] && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+                const T* src = ok ? xg + ((int64_t)(a_nH[i] + hi) * a.W + wi) * a.ldx + cic * CH : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if ((wave * 16 + 64 * j) < BN) {  // wave-uniform
+                const bool ok = b_ok[j] && kvalid;
+                const T* src = ok ? b_ptr[j] + (int64_t)(tap * a.cpt + cic) * CH : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+        cic += adv_c;
+        tap += adv_tap;
+        if (cic >= a.cpt) {
+            cic -= a.cpt;
+            ++tap;
+        }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nkt = (a.KC + 3) >> 2;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+        if (kt + 1 < nkt) issue((kt + 1) & 1);
+        const char* As = smem + (kt & 1) * STAGE;
+        Mma<T>::template step<TM, TN>(As, As + BM * 64, wm * TM * 16, wn * TN * 16, lane, acc);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    const int l15 = lane & 15, l4 = lane >> 4;
+    T* __restrict__ yg = reinterpret_cast<T*>(a.y);
+    int64_t yoff[TM];
+    bool mok[TM];
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + (wm * TM + tm) * 16 + l15;
+        mok[tm] = m < a.M;
+        const int mm = mok[tm] ? m : 0;
+        if (a.s_out == 1 && a.Hy == a.Ho && a.Wy == a.Wo) {
+            yoff[tm] = (int64_t)mm * a.ldy;
+        } else {
+            const int wo = mm % a.Wo;
+            const int t = mm / a.Wo;
+            const int ho = t % a.Ho;
+            const int n = t / a.Ho;
+            yoff[tm] = (((int64_t)n * a.Hy + ho * a.s_out + a.oh_off) * a.Wy + wo * a.s_out + a.ow_off) * a.ldy;
+        }
+    }
+
+    if constexpr (STATS) {
+        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int chl = (wn * TN + tn) * 16 + 4 * l4;  // channel within block tile
+            const int ch = n0 + chl;
+            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = to_f32(from_f32<T>(acc[tn][tm][r]));  // statistics of what is stored
+                    s1[r] += v[r];
+                    s2[r] += v[r] * v[r];
+                }
+                if (mok[tm]) {
+                    if (a.vec_store && ch + 3 < a.Cout) {
+                        Pack<T, 4>::store(yg + yoff[tm] + ch, v);
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ch + r < a.Cout) yg[yoff[tm] + ch + r] = from_f32<T>(v[r]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[r] += __shfl_xor(s1[r], o, 64);
+                    s2[r] += __shfl_xor(s2[r], o, 64);
+                }
+            }
+            if (l15 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(wm * 2 + 0) * BN + chl + r] = s1[r];
+                    red[(wm * 2 + 1) * BN + chl + r] = s2[r];
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < 2 * BN) {
+            const int which = tid / BN, chl = tid % BN;
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < WM; ++q) s += red[(q * 2 + which) * BN + chl];
+            const int ch = n0 + chl;
+            if (ch < a.Cout) a.partials[((int64_t)blockIdx.x * 2 + which) * a.Cout + ch] = s;
+        }
+    } else {
+        const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn) {
+            const int ch = n0 + (wn * TN + tn) * 16 + 4 * l4;
+            float sc[4], bi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool cok = ch + r < a.Cout;
+                sc[r] = (a.scale && cok) ? a.scale[ch + r] : 1.0f;
+                bi[r] = (a.bias && cok) ? a.bias[ch + r] : 0.0f;
+            }
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) {
+                if (!mok[tm]) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(acc[tn][tm][r] * sc[r] + bi[r], a.act);
+                if (a.vec_store && ch + 3 < a.Cout) {
+                    if (rg) {
+                        float rr[4];
+                        const int m = m0 + (wm * TM + tm) * 16 + l15;
+                        Pack<T, 4>::load(rg + (int64_t)m * a.ldres + ch, rr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                    }
+                    Pack<T, 4>::store(yg + yoff[tm] + ch, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (ch + r < a.Cout) {
+                            float o = v[r];
+                            if (rg) o += to_f32(rg[(int64_t)(m0 + (wm * TM + tm) * 16 + l15) * a.ldres + ch + r]);
+                            yg[yoff[tm] + ch + r] = from_f32<T>(o);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct TileChoice {
+    int bm, bn;
+};
+
+static TileChoice choose_tile(int64_t M, int64_t cout) {
+    TileChoice t;
+    t.bn = cout <= 32 ? 32 : (cout <= 64 ? 64 : 128);
+    t.bm = 128;
+    const int64_t blocks = ((M + 127) / 128) * ((cout + t.bn - 1) / t.bn);
+    if (blocks < 512 && t.bn >= 64) t.bm = 64;
+    return t;
+}
+
+template <typename T, bool STATS>
+static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) {
+    dim3 grid((a.M + t.bm - 1) / t.bm, (a.Cout + t.bn - 1) / t.bn);
+    const size_t lds = 2 * (size_t)(t.bm + t.bn) * 64;
+#define YMI_LAUNCH(BM, BN, WM, WN)                                                                           \
+    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, STATS>), grid, dim3(256), lds, stream, a)
+    if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2);
+    else if (t.bm == 128 && t.bn == 64) YMI_LAUNCH(128, 64, 2, 2);
+    else if (t.bm == 128 && t.bn == 32) YMI_LAUNCH(128, 32, 4, 1);
+    else if (t.bm == 64 && t.bn == 128) YMI_LAUNCH(64, 128, 2, 2);
+    else if (t.bm == 64 && t.bn == 64) YMI_LAUNCH(64, 64, 2, 2);
+    else {
+        ymi_set_error("igemm: no tile %dx%d", t.bm, t.bn);
+        return YMI_EINVAL;
+    }
+#undef YMI_LAUNCH
+    YMI_CHECK_LAUNCH("igemm");
+    return YMI_OK;
+}
+
+int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
+    TileChoice t = choose_tile(a.M, a.Cout);
+    if (host_blocks) *host_blocks = (a.M + t.bm - 1) / t.bm;
+    if (dtype == YMI_BF16) return stats ? launch_igemm_t<bf16_t, true>(a, t, stream) : launch_igemm_t<bf16_t, false>(a, t, stream);
+    return stats ? launch_igemm_t<float, true>(a, t, stream) : launch_igemm_t<float, false>(a, t, stream);
+}
+
+static void pack_taps(const int* dh, const int* dw, int n, uint64_t* pdh, uint64_t* pdw) {
+    uint64_t a = 0, b = 0;
+    for (int i = 0; i < n; ++i) {
+        a |= (uint64_t)((dh[i] + 8) & 15) << (4 * i);
+        b |= (uint64_t)((dw[i] + 8) & 15) << (4 * i);
+    }
+    *pdh = a;
+    *pdw = b;
+}
+
+extern "C" int64_t ymi_conv2d_stat_blocks(int64_t m_rows, int64_t cout) {
+    (void)cout;
+    return (m_rows + 63) / 64;  // smallest BM any tile choice uses
+}
+
+extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                              const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
+                              float* stat_partials, int64_t* host_stat_blocks, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(y) && w_packed, "conv2d_fwd: bad tensor");
+    YMI_CHECK_ARG(x->dtype == y->dtype, "conv2d_fwd: dtype mismatch");
+    const int ch = x->dtype == YMI_BF16 ? 8 : 4;
+    YMI_CHECK_ARG(x->c % ch == 0 && x->ld % ch == 0, "conv2d_fwd: input channels (%lld, ld %lld) must be a multiple of %d",
+                  (long long)x->c, (long long)x->ld, ch);
+    YMI_CHECK_ARG(((uintptr_t)x->data & 15) == 0 && ((uintptr_t)w_packed & 15) == 0, "conv2d_fwd: 16-byte alignment");
+    YMI_CHECK_ARG(kh == kw && (kh == 1 || kh == 3) && (stride == 1 || stride == 2), "conv2d_fwd: k in {1,3}, stride in {1,2}");
+    const int64_t pad = kh / 2;
+    const int64_t ho = (x->h + 2 * pad - kh) / stride + 1, wo = (x->w + 2 * pad - kw) / stride + 1;
+    YMI_CHECK_ARG(y->n == x->n && y->h == ho && y->w == wo && y->c == cout, "conv2d_fwd: output shape");
+    YMI_CHECK_ARG(x->n * ho * wo < (1ll << 31) && ymi_pixels(x) * x->ld < (1ll << 31) && ymi_pixels(y) * y->ld < (1ll << 31),
+                  "conv2d_fwd: tensor too large for 32-bit indexing");
+    if (residual) YMI_CHECK_ARG(ymi_tensor_ok(residual) && ymi_same_shape(residual, y) && residual->dtype == y->dtype, "conv2d_fwd: residual");
+    YMI_CHECK_ARG(!(stat_partials && (scale || bias || residual || act != YMI_ACT_NONE)), "conv2d_fwd: statistics mode stores the raw output");
+
+    IgemmArgs a{};
+    a.x = x->data; a.w = w_packed; a.y = y->data; a.res = residual ? residual->data : nullptr;
+    a.scale = scale; a.bias = bias; a.partials = stat_partials; a.zero = ymi_zero_page();
+    a.ldx = x->ld; a.ldy = y->ld; a.ldres = residual ? residual->ld : 0;
+    a.M = (int)(x->n * ho * wo); a.H = (int)x->h; a.W = (int)x->w; a.Ho = (int)ho; a.Wo = (int)wo; a.Hy = (int)ho; a.Wy = (int)wo;
+    a.s_in = (int)stride; a.s_out = 1; a.oh_off = 0; a.ow_off = 0;
+    a.Cout = (int)cout; a.cpt = (int)(x->c / ch); a.ntaps = (int)(kh * kw); a.KC = a.ntaps * a.cpt; a.ktot = (int64_t)a.KC * ch;
+    int dh[9], dw[9];
+    for (int i = 0; i < kh; ++i)
+        for (int j = 0; j < kw; ++j) { dh[i * kw + j] = i - (int)pad; dw[i * kw + j] = j - (int)pad; }
+    pack_taps(dh, dw, a.ntaps, &a.tap_dh, &a.tap_dw);
+    a.act = act;
+    const int g = 4;
+    a.vec_store = (y->ld % g == 0) && (((uintptr_t)y->data) % (g * ymi_esize(y->dtype)) == 0) &&
+                  (!residual || (residual->ld % g == 0 && ((uintptr_t)residual->data) % (g * ymi_esize(y->dtype)) == 0));
+    int blocks = 0;
+    int rc = ymi_launch_igemm(a, x->dtype, stat_partials != nullptr, &blocks, (hipStream_t)stream);
+    if (host_stat_blocks) *host_stat_blocks = blocks;
+    return rc;
+}
+
+// dx = sum over taps of dy (x) w : stride 1 -> one launch; stride 2 -> one launch per output parity class.
+extern "C" int64_t ymi_conv_dgrad_pack_elems(int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t stride) {
+    (void)stride;
+    return o * i * kh * kw;  // the classes partition the taps
+}
+
+extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw,
+                                   int64_t stride, const ymi_tensor* dx, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && w_dgrad_packed, "conv2d_bwd_data: bad tensor");
+    YMI_CHECK_ARG(dy->dtype == dx->dtype, "conv2d_bwd_data: dtype mismatch");
+    const int ch = dy->dtype == YMI_BF16 ? 8 : 4;
+    YMI_CHECK_ARG(dy->c % ch == 0 && dy->ld % ch == 0, "conv2d_bwd_data: dy channels must be a multiple of %d", ch);
+    YMI_CHECK_ARG(kh == kw && (kh == 1 || kh == 3) && (stride == 1 || stride == 2), "conv2d_bwd_data: k in {1,3}, stride in {1,2}");
+    const int64_t pad = kh / 2;
+    YMI_CHECK_ARG(dx->c == cin && dx->n == dy->n && dy->h == (dx->h + 2 * pad - kh) / stride + 1 && dy->w == (dx->w + 2 * pad - kw) / stride + 1,
+                  "conv2d_bwd_data: shapes");
+    YMI_CHECK_ARG(ymi_pixels(dx) * dx->ld < (1ll << 31) && ymi_pixels(dy) * dy->ld < (1ll << 31), "conv2d_bwd_data: too large");
+    const size_t es = ymi_esize(dy->dtype);
+    const char* wbase = reinterpret_cast<const char*>(w_dgrad_packed);
+    int64_t woff = 0;  // elements
+    const int nclass = stride == 1 ? 1 : 4;
+    for (int cls = 0; cls < nclass; ++cls) {
+        const int ph = stride == 1 ? 0 : cls / 2, pw = stride == 1 ? 0 : cls % 2;
+        int dh[9], dw[9], nt = 0;
+        for (int i = 0; i < kh; ++i)
+            for (int j = 0; j < kw; ++j) {
+                const int nh = ph + (int)pad - i, nw = pw + (int)pad - j;
+                if (nh % (int)stride != 0 || nw % (int)stride != 0) continue;
+                dh[nt] = nh / (int)stride; dw[nt] = nw / (int)stride; ++nt;
+            }
+        const int64_t ho = (dx->h - ph + stride - 1) / stride, wo = (dx->w - pw + stride - 1) / stride;
+        if (nt > 0 && ho > 0 && wo > 0) {
+            IgemmArgs a{};
+            a.x = dy->data; a.w = wbase + woff * es; a.y = dx->data; a.zero = ymi_zero_page();
+            a.ldx = dy->ld; a.ldy = dx->ld;
+            a.M = (int)(dx->n * ho * wo); a.H = (int)dy->h; a.W = (int)dy->w; a.Ho = (int)ho; a.Wo = (int)wo; a.Hy = (int)dx->h; a.Wy = (int)dx->w;
+            a.s_in = 1; a.s_out = (int)stride; a.oh_off = ph; a.ow_off = pw;
+            a.Cout = (int)cin; a.cpt = (int)(dy->c / ch); a.ntaps = nt; a.KC = nt * a.cpt; a.ktot = (int64_t)a.KC * ch;
+            pack_taps(dh, dw, nt, &a.tap_dh, &a.tap_dw);
+            a.act = YMI_ACT_NONE;
+            a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0);
+            int rc = ymi_launch_igemm(a, dy->dtype, false, nullptr, (hipStream_t)stream);
+            if (rc) return rc;
+        } else if (ho > 0 && wo > 0) {
+            ymi_set_error("conv2d_bwd_data: parity class without taps (k=1 stride=2 is not supported)");
+            return YMI_EINVAL;
+        }
+        woff += (int64_t)nt * dy->c * cin;
+    }
+    return YMI_OK;
+}

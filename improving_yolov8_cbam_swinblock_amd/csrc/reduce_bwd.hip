@@ -1,0 +1,267 @@
+// Per-channel reductions over NHWC tensors and the backward of act(BatchNorm_train(raw)).
+//
+// All reductions are two-stage and deterministic: stage 1 gives every workgroup a contiguous pixel
+// range and a fixed channel group per thread (coalesced 8/16-byte reads along C), accumulates in f32
+// registers and writes [block][2][C] partials; stage 2 sums the partials per channel in double.
+#include "common.h"
+
+struct RV {
+    const void* p;
+    int64_t ld;
+};
+
+// FN: 0 colsum(a)            -> s0 = sum a
+//     1 bn-act backward      -> dz = a * act'(z), z = (b-mean)*inv*gamma+beta ; s0 = sum dz, s1 = sum dz*xhat
+//     2 layernorm param grads-> s0 = sum a (dbeta), s1 = sum a * (b - mean_row)*rstd_row (dgamma); mean/rstd per ROW
+template <typename T, int FN>
+__global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   const float* __restrict__ mean, const float* __restrict__ inv, int act, float* __restrict__ part) {
+    extern __shared__ float red[];  // [rows][TG][8]
+    const int rows = 256 / TG;
+    const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
+    const int groups = C / 4;
+    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
+    const int64_t p0 = blockIdx.x * per, p1 = (p0 + per < P) ? p0 + per : P;
+    const T* ap = reinterpret_cast<const T*>(a.p);
+    const T* bp = reinterpret_cast<const T*>(b.p);
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    if (tx < groups) {
+        float g[4], be[4], mu[4], iv[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = tx * 4 + r;
+            g[r] = (FN == 1 && gamma) ? gamma[c] : 1.0f;
+            be[r] = (FN == 1 && beta) ? beta[c] : 0.0f;
+            mu[r] = (FN == 1) ? mean[c] : 0.0f;
+            iv[r] = (FN == 1) ? inv[c] : 1.0f;
+        }
+        for (int64_t p = p0 + ty; p < p1; p += rows) {
+            float va[4], vb[4];
+            Pack<T, 4>::load(ap + p * a.ld + tx * 4, va);
+            if (FN != 0) Pack<T, 4>::load(bp + p * b.ld + tx * 4, vb);
+            if (FN == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s0[r] += va[r];
+            } else if (FN == 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float xh = (vb[r] - mu[r]) * iv[r];
+                    const float dz = va[r] * act_grad_rt(xh * g[r] + be[r], act);
+                    s0[r] += dz;
+                    s1[r] += dz * xh;
+                }
+            } else {
+                const float m = mean[p], rs = inv[p];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    s0[r] += va[r];
+                    s1[r] += va[r] * (vb[r] - m) * rs;
+                }
+            }
+        }
+    }
+    float* my = red + ((size_t)ty * TG + tx) * 8;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        my[r] = s0[r];
+        my[4 + r] = s1[r];
+    }
+    __syncthreads();
+    if (ty == 0 && tx < groups) {
+        for (int q = 1; q < rows; ++q) {
+            const float* o = red + ((size_t)q * TG + tx) * 8;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s0[r] += o[r];
+                s1[r] += o[4 + r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            part[((int64_t)blockIdx.x * 2 + 0) * C + tx * 4 + r] = s0[r];
+            part[((int64_t)blockIdx.x * 2 + 1) * C + tx * 4 + r] = s1[r];
+        }
+    }
+}
+
+// stage 2: out0[c] = sum_b part[b][0][c] (* scale), out1[c] = sum_b part[b][1][c] (* scale)
+__global__ void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    double s0 = 0.0, s1 = 0.0;
+    if (c < C)
+        for (int b = slice; b < blocks; b += 4) {
+            s0 += (double)part[((int64_t)b * 2 + 0) * C + c];
+            s1 += (double)part[((int64_t)b * 2 + 1) * C + c];
+        }
+    red[0][slice][cl] = s0;
+    red[1][slice][cl] = s1;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        if (out0) out0[c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+        if (out1) out1[c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+static int pow2_ge(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+// returns number of stage-1 blocks; partials must hold blocks*2*C floats
+static int reduce_blocks(int64_t P) {
+    int64_t b = (P + 255) / 256;  // >= 256 pixels per block
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+template <int FN>
+static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const float* gamma, const float* beta, const float* mean,
+                              const float* inv, int act, float* part, int* blocks_out, hipStream_t stream, const char* what) {
+    const int64_t P = ymi_pixels(a);
+    const int C = (int)a->c;
+    YMI_CHECK_ARG(C % 4 == 0 && a->ld % 4 == 0 && C <= 1024 && (!b || (b->ld % 4 == 0)), "%s: channels must be a multiple of 4 and <= 1024", what);
+    const int TG = pow2_ge(C / 4) > 256 ? 256 : pow2_ge(C / 4);
+    const int blocks = reduce_blocks(P);
+    const size_t lds = (size_t)256 * 8 * sizeof(float);
+    RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
+    if (a->dtype == YMI_BF16)
+        hipLaunchKernelGGL((chan_reduce_kernel<bf16_t, FN>), dim3(blocks), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
+    else
+        hipLaunchKernelGGL((chan_reduce_kernel<float, FN>), dim3(blocks), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
+    YMI_CHECK_LAUNCH(what);
+    *blocks_out = blocks;
+    return YMI_OK;
+}
+
+int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream) {
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, part, blocks, C, out0, out1);
+    YMI_CHECK_LAUNCH("chan_reduce_final");
+    return YMI_OK;
+}
+
+extern "C" int ymi_colsum(const ymi_tensor* x, float* out, void* workspace, size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(x) && out && workspace, "colsum: args");
+    const size_t need = (size_t)reduce_blocks(ymi_pixels(x)) * 2 * x->c * sizeof(float);
+    if (workspace_bytes < need) {
+        ymi_set_error("colsum: workspace %zu < %zu", workspace_bytes, need);
+        return YMI_EWORKSPACE;
+    }
+    int blocks = 0;
+    int rc = launch_chan_reduce<0>(x, nullptr, nullptr, nullptr, nullptr, nullptr, 0, (float*)workspace, &blocks, (hipStream_t)stream, "colsum");
+    if (rc) return rc;
+    return ymi_chan_reduce_final((const float*)workspace, blocks, (int)x->c, out, nullptr, (hipStream_t)stream);
+}
+
+// LayerNorm parameter gradients (used by swin.hip): dgamma = sum_rows dy*xhat, dbeta = sum_rows dy
+int ymi_ln_param_grads(const ymi_tensor* dy, const ymi_tensor* x, const float* mean, const float* rstd, float* dgamma, float* dbeta,
+                       void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const size_t need = (size_t)reduce_blocks(ymi_pixels(dy)) * 2 * dy->c * sizeof(float);
+    if (workspace_bytes < need) {
+        ymi_set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, need);
+        return YMI_EWORKSPACE;
+    }
+    int blocks = 0;
+    int rc = launch_chan_reduce<2>(dy, x, nullptr, nullptr, mean, rstd, 0, (float*)workspace, &blocks, stream, "layernorm_bwd(param)");
+    if (rc) return rc;
+    return ymi_chan_reduce_final((const float*)workspace, blocks, (int)dy->c, dbeta, dgamma, stream);
+}
+
+// draw = gamma*inv*(dz - mean(dz) - xhat*mean(dz*xhat))
+template <typename T>
+__global__ void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t P, int C, const float* __restrict__ gamma,
+                                        const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ inv,
+                                        const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx, float inv_count, int act) {
+    const int groups = C / 4;
+    const int64_t total = P * groups;
+    const T* dp = reinterpret_cast<const T*>(dout.p);
+    const T* rp = reinterpret_cast<const T*>(raw.p);
+    T* op = reinterpret_cast<T*>(const_cast<void*>(draw.p));
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const int64_t p = i / groups;
+        float d[4], x[4], o[4];
+        Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
+        Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = g * 4 + r;
+            const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+            const float xh = (x[r] - mean[c]) * inv[c];
+            const float dz = d[r] * act_grad_rt(xh * ga + be, act);
+            o[r] = ga * inv[c] * (dz - sum_dz[c] * inv_count - xh * sum_dzx[c] * inv_count);
+        }
+        Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
+    }
+}
+
+extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
+                              const float* save_invstd, const float* beta, int32_t act, const ymi_tensor* draw, float* dgamma,
+                              float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(dout) && ymi_tensor_ok(raw) && ymi_tensor_ok(draw) && ymi_same_shape(dout, raw) && ymi_same_shape(dout, draw),
+                  "bn_act_bwd: shapes");
+    YMI_CHECK_ARG(dout->dtype == raw->dtype && raw->dtype == draw->dtype, "bn_act_bwd: dtypes");
+    YMI_CHECK_ARG(save_mean && save_invstd && dgamma && dbeta && workspace, "bn_act_bwd: null argument");
+    YMI_CHECK_ARG(draw->ld % 4 == 0, "bn_act_bwd: draw ld");
+    const int64_t P = ymi_pixels(dout);
+    const int C = (int)dout->c;
+    const size_t need = (size_t)reduce_blocks(P) * 2 * C * sizeof(float);
+    if (workspace_bytes < need) {
+        ymi_set_error("bn_act_bwd: workspace %zu < %zu", workspace_bytes, need);
+        return YMI_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = 0;
+    int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)");
+    if (rc) return rc;
+    rc = ymi_chan_reduce_final((const float*)workspace, blocks, C, dbeta, dgamma, s);  // dbeta = sum dz, dgamma = sum dz*xhat
+    if (rc) return rc;
+    const int64_t total = P * (C / 4);
+    int64_t gb = (total + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
+    if (dout->dtype == YMI_BF16)
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, 1.0f / (float)P, act);
+    else
+        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, 1.0f / (float)P, act);
+    YMI_CHECK_LAUNCH("bn_act_bwd(apply)");
+    return YMI_OK;
+}
+
+// dx = dy * gelu'(pre)
+template <typename T>
+__global__ void gelu_bwd_kernel(RV pre, RV dy, RV dx, int64_t P, int C) {
+    const int groups = C / 4;
+    const int64_t total = P * groups;
+    const T* pp = reinterpret_cast<const T*>(pre.p);
+    const T* dp = reinterpret_cast<const T*>(dy.p);
+    T* op = reinterpret_cast<T*>(const_cast<void*>(dx.p));
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const int64_t p = i / groups;
+        float a[4], d[4];
+        Pack<T, 4>::load(pp + p * pre.ld + g * 4, a);
+        Pack<T, 4>::load(dp + p * dy.ld + g * 4, d);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] *= gelu_grad_f(a[r]);
+        Pack<T, 4>::store(op + p * dx.ld + g * 4, d);
+    }
+}
+
+extern "C" int ymi_gelu_bwd(const ymi_tensor* pre, const ymi_tensor* dy, const ymi_tensor* dx, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(pre) && ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && ymi_same_shape(pre, dy) && ymi_same_shape(pre, dx), "gelu_bwd: shapes");
+    YMI_CHECK_ARG(pre->dtype == dy->dtype && dy->dtype == dx->dtype && pre->c % 4 == 0 && pre->ld % 4 == 0 && dy->ld % 4 == 0 && dx->ld % 4 == 0, "gelu_bwd: dtype/alignment");
+    const int64_t P = ymi_pixels(pre), total = P * (pre->c / 4);
+    int64_t gb = (total + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    RV a{pre->data, pre->ld}, b{dy->data, dy->ld}, o{dx->data, dx->ld};
+    if (pre->dtype == YMI_BF16)
+        hipLaunchKernelGGL(gelu_bwd_kernel<bf16_t>, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, a, b, o, P, (int)pre->c);
+    else
+        hipLaunchKernelGGL(gelu_bwd_kernel<float>, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, a, b, o, P, (int)pre->c);
+    YMI_CHECK_LAUNCH("gelu_bwd");
+    return YMI_OK;
+}

@@ -1,0 +1,35 @@
+// Library-level plumbing: version, thread-local error text, the device zero page.
+#include <stdarg.h>
+#include <string.h>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+void ymi_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" int ymi_version(void) { return YMI_VERSION; }
+extern "C" const char* ymi_last_error(void) { return g_err; }
+
+// 256 zero bytes in device memory; __device__ globals are zero-initialised when the code object loads.
+__device__ __attribute__((aligned(256))) unsigned char ymi_zero_page_storage[256];
+
+const void* ymi_zero_page() {
+    // one address per device; resolved once per process per device (no allocation, no sync afterwards)
+    static thread_local int cached_dev = -1;
+    static thread_local void* cached_ptr = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev != cached_dev) {
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ymi_zero_page_storage)) != hipSuccess) return nullptr;
+        cached_ptr = p;
+        cached_dev = dev;
+    }
+    return cached_ptr;
+}

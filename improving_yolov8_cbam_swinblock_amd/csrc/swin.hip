@@ -1,0 +1,622 @@
+// SwinBlock pieces (fork's nn/modules/swin_block.py) for NHWC tensors on gfx950.
+//
+//  * window_partition / window_reverse are pure index maps; since activations are already NHWC
+//    ('b c h w -> b h w c' is free) they are folded into the LayerNorm-1 load (gather, zero for
+//    padding pixels) and into the final store (scatter + crop).  Stand-alone copies and the integer
+//    index map exist for the bit-exact test.
+//  * LayerNorm: one wave per token, 16 bytes per lane, two-pass statistics in registers.
+//  * window attention: one workgroup (4 waves) per window, heads in sequence; every product is a
+//    16x16-tile "NT" MFMA (both operands K-contiguous rows in LDS, rows padded by 16 B so
+//    ds_read_b128 fragment reads are conflict-free); 49 tokens pad to 64 with zero rows, pad keys
+//    masked to -inf before the softmax; V (and, in backward, dO / Q / K) are transposed on the way
+//    into LDS.  Token GEMMs (QKV, proj, MLP) are ymi_conv2d_fwd with a 1x1 "kernel".
+#include "common.h"
+
+int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream);
+
+struct SV {
+    const void* p;
+    int64_t ld;
+};
+
+// token t (window order) -> pixel of the padded grid, -1 if outside the real image.  swin_block.py:8-13
+__device__ __forceinline__ int64_t token_pixel(int64_t t, int H, int W, int Hp, int Wp, int ws, bool* real) {
+    const int L = ws * ws;
+    const int nww = Wp / ws, nwh = Hp / ws;
+    const int tok = (int)(t % L);
+    const int64_t win = t / L;
+    const int ww = (int)(win % nww);
+    const int wh = (int)((win / nww) % nwh);
+    const int b = (int)(win / ((int64_t)nww * nwh));
+    const int h = wh * ws + tok / ws, w = ww * ws + tok % ws;
+    *real = (h < H) && (w < W);
+    return ((int64_t)b * H + h) * W + w;  // index in the UNPADDED image (valid only when *real)
+}
+
+__global__ void window_index_kernel(int64_t T, int Hp, int Wp, int ws, int* __restrict__ out) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < T; t += (int64_t)gridDim.x * blockDim.x) {
+        bool real;
+        out[t] = (int)token_pixel(t, Hp, Wp, Hp, Wp, ws, &real);  // padded grid: every token is "real"
+    }
+}
+
+extern "C" int ymi_window_partition_index(int64_t n, int64_t hp, int64_t wp, int64_t ws, int32_t* index, void* stream) {
+    YMI_CHECK_ARG(index && ws > 0 && hp % ws == 0 && wp % ws == 0 && n > 0, "window_partition_index: args");
+    const int64_t T = n * hp * wp;
+    YMI_CHECK_ARG(T < (1ll << 31), "window_partition_index: too many tokens");
+    hipLaunchKernelGGL(window_index_kernel, dim3((unsigned)((T + 255) / 256 > 4096 ? 4096 : (T + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       T, (int)hp, (int)wp, (int)ws, index);
+    YMI_CHECK_LAUNCH("window_partition_index");
+    return YMI_OK;
+}
+
+// DIR 0: tokens[t] = x[pixel(t)] (zeros for padding)   DIR 1: x[pixel(t)] = tokens[t] (padding dropped)
+template <typename T, int DIR>
+__global__ void window_move_kernel(SV x, SV tok, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C) {
+    const int groups = C / 4;
+    const int64_t total = Tn * groups;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int g = (int)(i % groups);
+        const int64_t t = i / groups;
+        bool real;
+        const int64_t px = token_pixel(t, H, W, Hp, Wp, ws, &real);
+        if (DIR == 0) {
+            float v[4] = {0.f, 0.f, 0.f, 0.f};
+            if (real) Pack<T, 4>::load(reinterpret_cast<const T*>(x.p) + px * x.ld + g * 4, v);
+            Pack<T, 4>::store(reinterpret_cast<T*>(const_cast<void*>(tok.p)) + t * tok.ld + g * 4, v);
+        } else if (real) {
+            float v[4];
+            Pack<T, 4>::load(reinterpret_cast<const T*>(tok.p) + t * tok.ld + g * 4, v);
+            Pack<T, 4>::store(reinterpret_cast<T*>(const_cast<void*>(x.p)) + px * x.ld + g * 4, v);
+        }
+    }
+}
+
+static int window_geometry(const ymi_tensor* x, int64_t ws, int64_t* Hp, int64_t* Wp) {
+    *Hp = (x->h + ws - 1) / ws * ws;
+    *Wp = (x->w + ws - 1) / ws * ws;
+    return 0;
+}
+
+template <int DIR>
+static int launch_window_move(const ymi_tensor* x, int64_t ws, const ymi_tensor* tokens, const char* what, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(tokens) && ws > 0, "%s: bad tensor", what);
+    int64_t Hp, Wp;
+    window_geometry(x, ws, &Hp, &Wp);
+    const int64_t T = x->n * Hp * Wp;
+    YMI_CHECK_ARG(ymi_pixels(tokens) == T && tokens->c == x->c && tokens->dtype == x->dtype, "%s: tokens must be [%lld, %lld]", what, (long long)T, (long long)x->c);
+    YMI_CHECK_ARG(x->c % 4 == 0 && x->ld % 4 == 0 && tokens->ld % 4 == 0, "%s: channels multiple of 4", what);
+    const int64_t total = T * (x->c / 4);
+    const unsigned gb = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    SV xv{x->data, x->ld}, tv{tokens->data, tokens->ld};
+    if (x->dtype == YMI_BF16)
+        hipLaunchKernelGGL((window_move_kernel<bf16_t, DIR>), dim3(gb), dim3(256), 0, (hipStream_t)stream, xv, tv, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c);
+    else
+        hipLaunchKernelGGL((window_move_kernel<float, DIR>), dim3(gb), dim3(256), 0, (hipStream_t)stream, xv, tv, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c);
+    YMI_CHECK_LAUNCH(what);
+    return YMI_OK;
+}
+extern "C" int ymi_window_partition(const ymi_tensor* x, int64_t ws, const ymi_tensor* tokens, void* stream) {
+    return launch_window_move<0>(x, ws, tokens, "window_partition", stream);
+}
+extern "C" int ymi_window_reverse(const ymi_tensor* tokens, int64_t ws, const ymi_tensor* x, void* stream) {
+    return launch_window_move<1>(x, ws, tokens, "window_reverse", stream);
+}
+
+// -------------------------------------------------------------------------------- LayerNorm
+constexpr int LN_MAXG = 4;  // C <= 64 lanes * 4 * LN_MAXG = 1024
+
+// one wave per token; ws > 0: rows are gathered from the NHWC image through the window map
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(SV x, SV out, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (t >= Tn) return;
+    bool real = true;
+    int64_t row = t;
+    if (ws > 0) row = token_pixel(t, H, W, Hp, Wp, ws, &real);
+    const T* xp = reinterpret_cast<const T*>(x.p) + row * x.ld;
+    float v[LN_MAXG][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXG; ++i) {
+        const int c = lane * 4 + 256 * i;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[i][r] = 0.f;
+        if (c < C && real) Pack<T, 4>::load(xp + c, v[i]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += v[i][r];
+    }
+    const float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXG; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) q += (v[i][r] - mu) * (v[i][r] - mu);
+    }
+    const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
+    T* op = reinterpret_cast<T*>(const_cast<void*>(out.p)) + t * out.ld;
+#pragma unroll
+    for (int i = 0; i < LN_MAXG; ++i) {
+        const int c = lane * 4 + 256 * i;
+        if (c < C) {
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (v[i][r] - mu) * rs * gamma[c + r] + beta[c + r];
+            Pack<T, 4>::store(op + c, o);
+        }
+    }
+    if (lane == 0) {
+        mean[t] = mu;
+        rstd[t] = rs;
+    }
+}
+
+extern "C" int ymi_layernorm_fwd(const ymi_tensor* x, int64_t ws, const float* gamma, const float* beta, float eps, const ymi_tensor* out,
+                                 float* mean, float* rstd, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(out) && gamma && beta && mean && rstd && x->dtype == out->dtype, "layernorm_fwd: args");
+    YMI_CHECK_ARG(x->c == out->c && x->c % 4 == 0 && x->c <= 1024 && x->ld % 4 == 0 && out->ld % 4 == 0, "layernorm_fwd: channels multiple of 4, <= 1024");
+    int64_t Hp = x->h, Wp = x->w;
+    if (ws > 0) window_geometry(x, ws, &Hp, &Wp);
+    const int64_t T = ws > 0 ? x->n * Hp * Wp : ymi_pixels(x);
+    YMI_CHECK_ARG(ymi_pixels(out) == T, "layernorm_fwd: output must hold %lld tokens", (long long)T);
+    SV xv{x->data, x->ld}, ov{out->data, out->ld};
+    dim3 grid((unsigned)((T + 3) / 4));
+    if (x->dtype == YMI_BF16)
+        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, xv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, beta, eps, mean, rstd);
+    else
+        hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, xv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, beta, eps, mean, rstd);
+    YMI_CHECK_LAUNCH("layernorm_fwd");
+    return YMI_OK;
+}
+
+// backward: dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); per-block partials of dgamma/dbeta.
+// ACCUM: dx += (used when the LayerNorm input also feeds a residual branch).
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, float* __restrict__ part, int accumulate) {
+    __shared__ float red[4][2][1024];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float ag[LN_MAXG][4], ab[LN_MAXG][4], g[LN_MAXG][4];
+#pragma unroll
+    for (int i = 0; i < LN_MAXG; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            ag[i][r] = 0.f;
+            ab[i][r] = 0.f;
+            const int c = lane * 4 + 256 * i + r;
+            g[i][r] = c < C ? gamma[c] : 0.f;
+        }
+    for (int64_t t = (int64_t)blockIdx.x * 4 + wv; t < Tn; t += (int64_t)gridDim.x * 4) {
+        bool real = true;
+        int64_t row = t;
+        if (ws > 0) row = token_pixel(t, H, W, Hp, Wp, ws, &real);
+        const T* xp = reinterpret_cast<const T*>(x.p) + row * x.ld;
+        const T* dp = reinterpret_cast<const T*>(dy.p) + t * dy.ld;
+        const float mu = mean[t], rs = rstd[t];
+        float xh[LN_MAXG][4], d[LN_MAXG][4];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < LN_MAXG; ++i) {
+            const int c = lane * 4 + 256 * i;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { xh[i][r] = 0.f; d[i][r] = 0.f; }
+            if (c < C) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (real) Pack<T, 4>::load(xp + c, v);
+                Pack<T, 4>::load(dp + c, d[i]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    xh[i][r] = (v[r] - mu) * rs;
+                    ag[i][r] += d[i][r] * xh[i][r];
+                    ab[i][r] += d[i][r];
+                    const float gd = g[i][r] * d[i][r];
+                    s1 += gd;
+                    s2 += gd * xh[i][r];
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)C;
+        s2 = wave_sum(s2) / (float)C;
+        if (real) {
+            T* op = reinterpret_cast<T*>(const_cast<void*>(dx.p)) + row * dx.ld;
+#pragma unroll
+            for (int i = 0; i < LN_MAXG; ++i) {
+                const int c = lane * 4 + 256 * i;
+                if (c < C) {
+                    float o[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] * d[i][r] - s1 - xh[i][r] * s2);
+                    if (accumulate) {
+                        float prev[4];
+                        Pack<T, 4>::load(op + c, prev);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] += prev[r];
+                    }
+                    Pack<T, 4>::store(op + c, o);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < LN_MAXG; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = lane * 4 + 256 * i + r;
+            red[wv][0][c] = ab[i][r];
+            red[wv][1][c] = ag[i][r];
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        part[((int64_t)blockIdx.x * 2 + 0) * C + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
+        part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+    }
+}
+
+static int ln_bwd_blocks(int64_t T) {
+    int64_t b = (T + 31) / 32;  // >= 8 tokens per wave
+    if (b > 512) b = 512;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+extern "C" int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tensor* dout, const float* gamma, const float* mean,
+                                 const float* rstd, const ymi_tensor* dx, int32_t accumulate, float* dgamma, float* dbeta, void* workspace,
+                                 size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(dout) && ymi_tensor_ok(dx) && gamma && mean && rstd && dgamma && dbeta && workspace, "layernorm_bwd: args");
+    YMI_CHECK_ARG(x->dtype == dout->dtype && x->dtype == dx->dtype && ymi_same_shape(x, dx), "layernorm_bwd: dtypes/shapes");
+    YMI_CHECK_ARG(x->c == dout->c && x->c % 4 == 0 && x->c <= 1024 && x->ld % 4 == 0 && dout->ld % 4 == 0 && dx->ld % 4 == 0, "layernorm_bwd: channels");
+    int64_t Hp = x->h, Wp = x->w;
+    if (ws > 0) window_geometry(x, ws, &Hp, &Wp);
+    const int64_t T = ws > 0 ? x->n * Hp * Wp : ymi_pixels(x);
+    YMI_CHECK_ARG(ymi_pixels(dout) == T, "layernorm_bwd: dout must hold %lld tokens", (long long)T);
+    const int blocks = ln_bwd_blocks(T);
+    const size_t need = (size_t)blocks * 2 * x->c * sizeof(float);
+    if (workspace_bytes < need) {
+        ymi_set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, need);
+        return YMI_EWORKSPACE;
+    }
+    SV xv{x->data, x->ld}, dv{dout->data, dout->ld}, ov{dx->data, dx->ld};
+    hipStream_t s = (hipStream_t)stream;
+    if (x->dtype == YMI_BF16)
+        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
+    else
+        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
+    YMI_CHECK_LAUNCH("layernorm_bwd");
+    return ymi_chan_reduce_final((const float*)workspace, blocks, (int)x->c, dbeta, dgamma, s);
+}
+
+// --------------------------------------------------------------------------- window attention
+template <typename T> struct AT;
+template <> struct AT<bf16_t> {
+    static constexpr int PAD = 8;   // elements (16 B)
+    static constexpr int KS = 32;   // k per MFMA step
+    // acc += A[arow + i][k0..] . B[brow + j][k0..]   (i = 4*(lane>>4)+r, j = lane&15)
+    static __device__ __forceinline__ void mma(const char* A, int astride, int arow, const char* B, int bstride, int brow, int klen, int lane, f32x4& acc) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        for (int k0 = 0; k0 < klen; k0 += 32) {
+            const bf16x8 a = *reinterpret_cast<const bf16x8*>(A + (size_t)(arow + l15) * astride + (k0 + 8 * l4) * 2);
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(B + (size_t)(brow + l15) * bstride + (k0 + 8 * l4) * 2);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc, 0, 0, 0);
+        }
+    }
+};
+template <> struct AT<float> {
+    static constexpr int PAD = 4;
+    static constexpr int KS = 4;
+    static __device__ __forceinline__ void mma(const char* A, int astride, int arow, const char* B, int bstride, int brow, int klen, int lane, f32x4& acc) {
+        const int l15 = lane & 15, l4 = lane >> 4;
+        for (int k0 = 0; k0 < klen; k0 += 4) {
+            const float a = *reinterpret_cast<const float*>(A + (size_t)(arow + l15) * astride + (k0 + l4) * 4);
+            const float b = *reinterpret_cast<const float*>(B + (size_t)(brow + l15) * bstride + (k0 + l4) * 4);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+        }
+    }
+};
+
+// G[r][c] = src[(r)*ld + c] for r < L, c < hd; zero elsewhere.  G rows: 64, cols: hdp, stride (hdp+PAD)
+template <typename T>
+__device__ __forceinline__ void lds_load_rows(char* G, const T* src, int64_t ld, int L, int hd, int hdp) {
+    const int stride = (hdp + AT<T>::PAD) * (int)sizeof(T);
+    const int g4 = hdp / 4;
+    for (int i = threadIdx.x; i < 64 * g4; i += 256) {
+        const int r = i / g4, c = (i % g4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < L && c < hd) Pack<T, 4>::load(src + (int64_t)r * ld + c, v);
+        Pack<T, 4>::store(reinterpret_cast<T*>(G + (size_t)r * stride) + c, v);
+    }
+}
+// G[c][r] = src[r*ld + c]: rows hdp, cols 64, stride (64+PAD)
+template <typename T>
+__device__ __forceinline__ void lds_load_transposed(char* G, const T* src, int64_t ld, int L, int hd, int hdp) {
+    const int stride = (64 + AT<T>::PAD) * (int)sizeof(T);
+    const int g4 = hdp / 4;
+    for (int i = threadIdx.x; i < 64 * g4; i += 256) {
+        const int r = i / g4, c = (i % g4) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (r < L && c < hd) Pack<T, 4>::load(src + (int64_t)r * ld + c, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) reinterpret_cast<T*>(G + (size_t)(c + e) * stride)[r] = from_f32<T>(v[e]);
+    }
+}
+
+struct AttnArgs {
+    SV qkv, out, dout, dqkv;
+    float* lse;
+    int L, heads, C, hd, hdp;
+    float scale;
+};
+
+constexpr int ATT_MAXDT = 12;  // head_dim <= 192
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_attn_fwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = (int)sizeof(T);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int hdp = a.hdp, L = a.L;
+    const int rstride = (hdp + AT<T>::PAD) * ES, tstride = (64 + AT<T>::PAD) * ES;
+    const size_t gsz = (size_t)((64 * rstride > hdp * tstride) ? 64 * rstride : hdp * tstride);
+    char* G1 = smem;
+    char* G2 = G1 + gsz;
+    char* P = G2 + gsz;  // [64][64+PAD]
+    const int64_t t0 = (int64_t)blockIdx.x * L;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
+    T* out = reinterpret_cast<T*>(const_cast<void*>(a.out.p)) + t0 * a.out.ld;
+    const int ndt = (a.hd + 15) / 16;
+
+    for (int head = 0; head < a.heads; ++head) {
+        const int co = head * a.hd;
+        lds_load_rows<T>(G1, qkv + co, a.qkv.ld, L, a.hd, hdp);            // Q
+        lds_load_rows<T>(G2, qkv + a.C + co, a.qkv.ld, L, a.hd, hdp);      // K
+        __syncthreads();
+        // S^T tiles: A = K rows (i = key), B = Q rows (j = query): this wave owns queries 16*wv..+15
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            AT<T>::mma(G2, rstride, t * 16, G1, rstride, wv * 16, hdp, lane, s[t]);
+        }
+        // lane holds query m = 16*wv + l15, keys j = 16t + 4*l4 + r
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * l4 + r;
+                s[t][r] = j < L ? s[t][r] * a.scale : -__builtin_inff();
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = __expf(s[t][r] - mx);
+                sum += s[t][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        const int m = 16 * wv + l15;
+        if (l4 == 0 && m < L && a.lse) a.lse[(t0 + m) * a.heads + head] = mx + __logf(sum);
+        __syncthreads();  // everyone is done reading G1 (Q) / G2 (K)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float p[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r] = s[t][r] * inv;
+            Pack<T, 4>::store(reinterpret_cast<T*>(P + (size_t)m * tstride) + 16 * t + 4 * l4, p);
+        }
+        lds_load_transposed<T>(G1, qkv + 2 * a.C + co, a.qkv.ld, L, a.hd, hdp);  // V^T
+        __syncthreads();
+        // O tiles: A = P rows (i = query), B = V^T rows (j = d)
+#pragma unroll
+        for (int dt = 0; dt < ATT_MAXDT; ++dt) {
+            if (dt < ndt) {
+                f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+                AT<T>::mma(P, tstride, wv * 16, G1, tstride, dt * 16, 64, lane, o);
+                const int d = dt * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int mq = wv * 16 + 4 * l4 + r;
+                    if (mq < L && d < a.hd) out[(int64_t)mq * a.out.ld + co + d] = from_f32<T>(o[r]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_attn_bwd_kernel(AttnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ES = (int)sizeof(T);
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int hdp = a.hdp, L = a.L;
+    const int rstride = (hdp + AT<T>::PAD) * ES, tstride = (64 + AT<T>::PAD) * ES;
+    const size_t gsz = (size_t)((64 * rstride > hdp * tstride) ? 64 * rstride : hdp * tstride);
+    char* G1 = smem;
+    char* G2 = G1 + gsz;
+    char* PT = G2 + gsz;                     // P^T   [key][query]
+    char* DS = PT + (size_t)64 * tstride;    // dS    [query][key]   (scale folded in)
+    char* DST = DS + (size_t)64 * tstride;   // dS^T  [key][query]
+    float* delta = reinterpret_cast<float*>(DST + (size_t)64 * tstride);  // [64]
+    const int64_t t0 = (int64_t)blockIdx.x * L;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
+    const T* o = reinterpret_cast<const T*>(a.out.p) + t0 * a.out.ld;
+    const T* dO = reinterpret_cast<const T*>(a.dout.p) + t0 * a.dout.ld;
+    T* dqkv = reinterpret_cast<T*>(const_cast<void*>(a.dqkv.p)) + t0 * a.dqkv.ld;
+    const int ndt = (a.hd + 15) / 16;
+
+    for (int head = 0; head < a.heads; ++head) {
+        const int co = head * a.hd;
+        lds_load_rows<T>(G1, qkv + co, a.qkv.ld, L, a.hd, hdp);        // Q
+        lds_load_rows<T>(G2, qkv + a.C + co, a.qkv.ld, L, a.hd, hdp);  // K
+        // delta[m] = sum_d dO[m][d] * O[m][d] : one wave per row, 16 rows per wave
+        for (int m = wv; m < 64; m += 4) {
+            float acc = 0.f;
+            if (m < L)
+                for (int d = lane; d < a.hd; d += 64) acc += to_f32(dO[(int64_t)m * a.dout.ld + co + d]) * to_f32(o[(int64_t)m * a.out.ld + co + d]);
+            acc = wave_sum(acc);
+            if (lane == 0) delta[m] = acc;
+        }
+        __syncthreads();
+        // S tiles: A = Q rows (i = query m), B = K rows (j = key): this wave owns queries 16*wv..+15
+        f32x4 s[4], dp[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            AT<T>::mma(G1, rstride, wv * 16, G2, rstride, t * 16, hdp, lane, s[t]);
+        }
+        __syncthreads();
+        lds_load_rows<T>(G1, dO + co, a.dout.ld, L, a.hd, hdp);             // dO
+        lds_load_rows<T>(G2, qkv + 2 * a.C + co, a.qkv.ld, L, a.hd, hdp);   // V
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            AT<T>::mma(G1, rstride, wv * 16, G2, rstride, t * 16, hdp, lane, dp[t]);
+        }
+        // lane holds queries m = 16*wv + 4*l4 + r, key j = 16t + l15
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = 16 * t + l15;
+            float p[4], ds[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * wv + 4 * l4 + r;
+                const bool ok = (j < L) && (m < L);
+                const float lse = ok ? a.lse[(t0 + m) * a.heads + head] : 0.f;
+                p[r] = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
+                ds[r] = ok ? p[r] * (dp[t][r] - delta[m]) * a.scale : 0.f;
+                reinterpret_cast<T*>(DS + (size_t)m * tstride)[j] = from_f32<T>(ds[r]);
+            }
+            Pack<T, 4>::store(reinterpret_cast<T*>(PT + (size_t)j * tstride) + 16 * wv + 4 * l4, p);
+            Pack<T, 4>::store(reinterpret_cast<T*>(DST + (size_t)j * tstride) + 16 * wv + 4 * l4, ds);
+        }
+        __syncthreads();
+        // dV[j][d] = sum_m P^T[j][m] dO^T[d][m]
+        lds_load_transposed<T>(G1, dO + co, a.dout.ld, L, a.hd, hdp);
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < ATT_MAXDT; ++dt)
+            if (dt < ndt) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                AT<T>::mma(PT, tstride, wv * 16, G1, tstride, dt * 16, 64, lane, acc);
+                const int d = dt * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = wv * 16 + 4 * l4 + r;
+                    if (j < L && d < a.hd) dqkv[(int64_t)j * a.dqkv.ld + 2 * a.C + co + d] = from_f32<T>(acc[r]);
+                }
+            }
+        __syncthreads();
+        // dK[j][d] = sum_m dS^T[j][m] Q^T[d][m]
+        lds_load_transposed<T>(G1, qkv + co, a.qkv.ld, L, a.hd, hdp);
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < ATT_MAXDT; ++dt)
+            if (dt < ndt) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                AT<T>::mma(DST, tstride, wv * 16, G1, tstride, dt * 16, 64, lane, acc);
+                const int d = dt * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int j = wv * 16 + 4 * l4 + r;
+                    if (j < L && d < a.hd) dqkv[(int64_t)j * a.dqkv.ld + a.C + co + d] = from_f32<T>(acc[r]);
+                }
+            }
+        __syncthreads();
+        // dQ[m][d] = sum_j dS[m][j] K^T[d][j]
+        lds_load_transposed<T>(G1, qkv + a.C + co, a.qkv.ld, L, a.hd, hdp);
+        __syncthreads();
+#pragma unroll
+        for (int dt = 0; dt < ATT_MAXDT; ++dt)
+            if (dt < ndt) {
+                f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+                AT<T>::mma(DS, tstride, wv * 16, G1, tstride, dt * 16, 64, lane, acc);
+                const int d = dt * 16 + l15;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = wv * 16 + 4 * l4 + r;
+                    if (m < L && d < a.hd) dqkv[(int64_t)m * a.dqkv.ld + co + d] = from_f32<T>(acc[r]);
+                }
+            }
+        __syncthreads();
+    }
+}
+
+static int attn_common(const ymi_tensor* qkv, int64_t wlen, int64_t heads, AttnArgs* a, size_t* lds, bool bwd, const char* what) {
+    YMI_CHECK_ARG(ymi_tensor_ok(qkv) && wlen > 0 && heads > 0, "%s: args", what);
+    YMI_CHECK_ARG(qkv->c % 3 == 0, "%s: qkv must have 3C channels", what);
+    const int64_t C = qkv->c / 3;
+    YMI_CHECK_ARG(C % heads == 0, "%s: C %% heads", what);
+    const int64_t hd = C / heads;
+    YMI_CHECK_ARG(wlen <= 64, "%s: window of %lld tokens exceeds the 64-token tile of this kernel", what, (long long)wlen);
+    YMI_CHECK_ARG(hd % 4 == 0 && hd <= 16 * ATT_MAXDT && qkv->ld % 4 == 0, "%s: head_dim must be a multiple of 4 and <= %d", what, 16 * ATT_MAXDT);
+    YMI_CHECK_ARG(ymi_pixels(qkv) % wlen == 0, "%s: token count not a multiple of the window length", what);
+    a->L = (int)wlen; a->heads = (int)heads; a->C = (int)C; a->hd = (int)hd; a->hdp = (int)((hd + 31) / 32 * 32);
+    a->scale = 1.0f / sqrtf((float)hd);
+    const int es = (int)ymi_esize(qkv->dtype), pad = qkv->dtype == YMI_BF16 ? 8 : 4;
+    const size_t rs = (size_t)(a->hdp + pad) * es, ts = (size_t)(64 + pad) * es;
+    const size_t gsz = 64 * rs > a->hdp * ts ? 64 * rs : a->hdp * ts;
+    *lds = 2 * gsz + (bwd ? 3 : 1) * 64 * ts + (bwd ? 64 * sizeof(float) : 0);
+    if (*lds > 160 * 1024) {
+        ymi_set_error("%s: head_dim %lld needs %zu B of LDS (> 160 KiB) in this dtype", what, (long long)hd, *lds);
+        return YMI_EINVAL;
+    }
+    return YMI_OK;
+}
+
+extern "C" int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int64_t heads, const ymi_tensor* out, float* lse, void* stream) {
+    AttnArgs a{};
+    size_t lds = 0;
+    int rc = attn_common(qkv, wlen, heads, &a, &lds, false, "window_attention_fwd");
+    if (rc) return rc;
+    YMI_CHECK_ARG(ymi_tensor_ok(out) && out->c == a.C && ymi_pixels(out) == ymi_pixels(qkv) && out->dtype == qkv->dtype, "window_attention_fwd: out");
+    a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.lse = lse;
+    dim3 grid((unsigned)(ymi_pixels(qkv) / wlen));
+    if (qkv->dtype == YMI_BF16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(window_attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(window_attn_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
+    YMI_CHECK_LAUNCH("window_attention_fwd");
+    return YMI_OK;
+}
+
+extern "C" int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor* out, const ymi_tensor* dout, const float* lse, int64_t wlen,
+                                        int64_t heads, const ymi_tensor* dqkv, void* stream) {
+    AttnArgs a{};
+    size_t lds = 0;
+    int rc = attn_common(qkv, wlen, heads, &a, &lds, true, "window_attention_bwd");
+    if (rc) return rc;
+    YMI_CHECK_ARG(ymi_tensor_ok(out) && ymi_tensor_ok(dout) && ymi_tensor_ok(dqkv) && lse, "window_attention_bwd: args");
+    YMI_CHECK_ARG(out->c == a.C && dout->c == a.C && dqkv->c == 3 * a.C && out->dtype == qkv->dtype && dout->dtype == qkv->dtype && dqkv->dtype == qkv->dtype,
+                  "window_attention_bwd: shapes/dtypes");
+    YMI_CHECK_ARG(ymi_pixels(out) == ymi_pixels(qkv) && ymi_pixels(dout) == ymi_pixels(qkv) && ymi_pixels(dqkv) == ymi_pixels(qkv), "window_attention_bwd: token counts");
+    a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.dout = SV{dout->data, dout->ld}; a.dqkv = SV{dqkv->data, dqkv->ld};
+    a.lse = const_cast<float*>(lse);
+    dim3 grid((unsigned)(ymi_pixels(qkv) / wlen));
+    if (qkv->dtype == YMI_BF16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(window_attn_bwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
+    YMI_CHECK_LAUNCH("window_attention_bwd");
+    return YMI_OK;
+}

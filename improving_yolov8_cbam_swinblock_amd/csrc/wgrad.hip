@@ -1,0 +1,288 @@
+// Weight gradient of the NHWC convolution as a split-K MFMA GEMM:
+//
+//   dW[co][(tap, ci)] = sum over output pixels m of  dY[m][co] * X[pixel(m, tap)][ci]
+//
+// Both operands are "K-major" in memory (the reduction index m is the slow one), so tiles are staged
+// in LDS exactly as they lie in HBM ([pixel][channel] rows, filled by 16-byte LDS-DMA) and the MFMA
+// fragments are read TRANSPOSED with ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32 parity
+// mode, 16x16x4 MFMA).  The pixel axis is split across workgroups (grid.z); each split writes an f32
+// slab, a second kernel sums the slabs in a fixed order (deterministic, no atomics) and scatters into
+// the reference's OIHW layout.
+#include "common.h"
+
+int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream);
+
+struct WgradArgs {
+    const void* x;
+    const void* dy;
+    float* slab;
+    const void* zero;
+    int64_t ldx, ldy;
+    int Mpix, H, W, Ho, Wo;
+    int stride, pad, KW;
+    int CoutP, Cin, NG;
+    int pix_per_split;
+};
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+constexpr int WG_BM = 64;    // rows  (co)
+constexpr int WG_BN = 128;   // cols  ((tap, ci))
+constexpr int WG_BK = 32;    // pixels per K step
+
+template <typename T> struct WFrag;
+template <> struct WFrag<bf16_t> {
+    // fragment of 8 k-values (pixels 8g..8g+7) for column c0+i of a [pixel][col] LDS image with `rowb` bytes per row
+    static __device__ __forceinline__ bf16x8 load(const char* img, int rowb, int c0, int lane) {
+        const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+        const char* a0 = img + (8 * g + q) * rowb + (c0 + 4 * p) * 2;
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * rowb));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    }
+    template <int TR, int TC>
+    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
+        bf16x8 af[TR], bfr[TC];
+#pragma unroll
+        for (int t = 0; t < TR; ++t) af[t] = load(Ys, WG_BM * 2, r0 + t * 16, lane);
+#pragma unroll
+        for (int t = 0; t < TC; ++t) bfr[t] = load(Xs, WG_BN * 2, c0 + t * 16, lane);
+#pragma unroll
+        for (int a = 0; a < TR; ++a)
+#pragma unroll
+            for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+};
+template <> struct WFrag<float> {
+    template <int TR, int TC>
+    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
+        const int kq = lane >> 4, i = lane & 15;
+#pragma unroll
+        for (int ks = 0; ks < WG_BK / 4; ++ks) {
+            float af[TR], bfr[TC];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) af[t] = *reinterpret_cast<const float*>(Ys + ((4 * ks + kq) * WG_BM + r0 + t * 16 + i) * 4);
+#pragma unroll
+            for (int t = 0; t < TC; ++t) bfr[t] = *reinterpret_cast<const float*>(Xs + ((4 * ks + kq) * WG_BN + c0 + t * 16 + i) * 4);
+#pragma unroll
+            for (int a = 0; a < TR; ++a)
+#pragma unroll
+                for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
+    }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+    constexpr int CH = ElemTraits<T>::CH;
+    constexpr int ES = (int)sizeof(T);
+    constexpr int YCW = WG_BM * ES / 16, XCW = WG_BN * ES / 16;        // 16-byte chunks per tile row
+    constexpr int NY = WG_BK * YCW / 256, NX = WG_BK * XCW / 256;     // chunks per thread per K step
+    constexpr int YBYTES = WG_BK * WG_BM * ES, XBYTES = WG_BK * WG_BN * ES;
+    constexpr int STAGE = YBYTES + XBYTES;
+    static_assert(NY >= 1 && NX >= 1, "tile too small");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int j0 = blockIdx.x * WG_BN, co0 = blockIdx.y * WG_BM;
+    const int m_begin = blockIdx.z * a.pix_per_split;
+    const int m_end = min(a.Mpix, m_begin + a.pix_per_split);
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ yg = reinterpret_cast<const T*>(a.dy);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+
+    // dY loader: thread -> (row, chunk) ; chunk column fixed per thread
+    const int ycc = tid % YCW;
+    const bool y_cok = co0 + ycc * CH < a.CoutP;
+    // X loader: column chunk fixed per thread -> fixed tap / input-channel offset
+    const int xcc = tid % XCW;
+    const int j = j0 + xcc * CH;
+    const bool x_cok = j < a.NG;
+    const int tap = x_cok ? j / a.Cin : 0;
+    const int ci = x_cok ? j - tap * a.Cin : 0;
+    const int dh = tap / a.KW - a.pad, dw = tap % a.KW - a.pad;
+    int xn[NX], xh[NX], xw[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int row = tid / XCW + i * (256 / XCW);
+        const int m = m_begin + row;
+        xw[i] = m % a.Wo;
+        const int t = m / a.Wo;
+        xh[i] = t % a.Ho;
+        xn[i] = t / a.Ho;
+    }
+
+    auto issue = [&](int s, int mk) {
+        char* Ys = smem + s * STAGE;
+        char* Xs = Ys + YBYTES;
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int row = tid / YCW + i * (256 / YCW);
+            const int m = mk + row;
+            const bool ok = y_cok && m < m_end;
+            const T* src = ok ? yg + (int64_t)m * a.ldy + co0 + ycc * CH : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = tid / XCW + i * (256 / XCW);
+            const int m = mk + row;
+            const int hi = xh[i] * a.stride + dh, wi = xw[i] * a.stride + dw;
+            const bool ok = x_cok && m < m_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const T* src = ok ? xg + ((int64_t)(xn[i] * a.H + hi) * a.W + wi) * a.ldx + ci : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            // advance this row's pixel by one K step
+            xw[i] += WG_BK;
+            while (xw[i] >= a.Wo) {
+                xw[i] -= a.Wo;
+                if (++xh[i] >= a.Ho) {
+                    xh[i] = 0;
+                    ++xn[i];
+                }
+            }
+        }
+    };
+
+    constexpr int TR = 2, TC = 4;  // per wave: 32 rows x 64 cols
+    f32x4 acc[TR][TC];
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (m_end - m_begin + WG_BK - 1) / WG_BK;
+    if (nk > 0) {
+        issue(0, m_begin);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            if (kt + 1 < nk) issue((kt + 1) & 1, m_begin + (kt + 1) * WG_BK);
+            const char* Ys = smem + (kt & 1) * STAGE;
+            WFrag<T>::template step<TR, TC>(Ys, Ys + YBYTES, wr * 32, wc * 64, lane, acc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    }
+
+    float* slab = a.slab + (int64_t)blockIdx.z * a.CoutP * a.NG;
+    const int l15 = lane & 15, l4 = lane >> 4;
+#pragma unroll
+    for (int r = 0; r < TR; ++r)
+#pragma unroll
+        for (int c = 0; c < TC; ++c) {
+            const int col = j0 + wc * 64 + c * 16 + l15;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + wr * 32 + r * 16 + 4 * l4 + e;
+                if (co < a.CoutP && col < a.NG) slab[(int64_t)co * a.NG + col] = acc[r][c][e];
+            }
+        }
+}
+
+// dw[co][ci][kh][kw] = sum_s slab[s][co][tap*Cin + ci]
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real, int cin_real,
+                                    int ntaps, float* __restrict__ dw) {
+    const int64_t total = (int64_t)cout_real * ntaps * cin_real;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % cin_real);
+        int64_t t = idx / cin_real;
+        const int tap = (int)(t % ntaps);
+        const int co = (int)(t / ntaps);
+        const int64_t off = (int64_t)co * NG + tap * Cin + ci;
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * CoutP * NG + off];
+        dw[((int64_t)co * cin_real + ci) * ntaps + tap] = s;
+    }
+}
+
+struct WgradPlan {
+    int splits, pix_per_split;
+    size_t slab_bytes;
+};
+static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng) {
+    const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + WG_BM - 1) / WG_BM);
+    int64_t s = (1024 + tiles - 1) / tiles;
+    const int64_t smax = (mpix + 255) / 256;
+    if (s > smax) s = smax;
+    if (s < 1) s = 1;
+    int64_t pps = (mpix + s - 1) / s;
+    pps = (pps + WG_BK - 1) / WG_BK * WG_BK;
+    s = (mpix + pps - 1) / pps;
+    WgradPlan p;
+    p.splits = (int)s;
+    p.pix_per_split = (int)pps;
+    p.slab_bytes = (size_t)s * coutp * ng * sizeof(float);
+    return p;
+}
+
+static int64_t pad_to(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
+
+extern "C" size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, int64_t cin, int64_t kh, int64_t kw) {
+    // upper bound over both dtypes' channel padding (8), plus room for the bias-gradient partials
+    const int64_t coutp = pad_to(cout, 8), cinp = pad_to(cin, 8);
+    WgradPlan p = wgrad_plan(m_rows, coutp, kh * kw * cinp);
+    return p.slab_bytes + (size_t)(1024 * 2 + 1) * coutp * sizeof(float) + 256;
+}
+
+extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
+                                     int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(dy) && dw_oihw && workspace, "conv2d_bwd_weight: bad argument");
+    YMI_CHECK_ARG(x->dtype == dy->dtype, "conv2d_bwd_weight: dtype mismatch");
+    const int ch = x->dtype == YMI_BF16 ? 8 : 4;
+    YMI_CHECK_ARG(x->c % ch == 0 && x->ld % ch == 0 && dy->c % ch == 0 && dy->ld % ch == 0, "conv2d_bwd_weight: channels must be multiples of %d", ch);
+    YMI_CHECK_ARG(kh == kw && (kh == 1 || kh == 3) && (stride == 1 || stride == 2), "conv2d_bwd_weight: k in {1,3}, stride in {1,2}");
+    const int64_t pad = kh / 2;
+    YMI_CHECK_ARG(dy->n == x->n && dy->h == (x->h + 2 * pad - kh) / stride + 1 && dy->w == (x->w + 2 * pad - kw) / stride + 1, "conv2d_bwd_weight: shapes");
+    YMI_CHECK_ARG(cout_real <= dy->c && cin_real <= x->c, "conv2d_bwd_weight: real channel counts");
+    YMI_CHECK_ARG(ymi_pixels(x) * x->ld < (1ll << 31) && ymi_pixels(dy) * dy->ld < (1ll << 31), "conv2d_bwd_weight: too large");
+    const int64_t mpix = ymi_pixels(dy);
+    const int64_t ng = kh * kw * x->c;
+    WgradPlan p = wgrad_plan(mpix, dy->c, ng);
+    size_t need = p.slab_bytes + (dbias ? (size_t)(1024 * 2 + 1) * dy->c * sizeof(float) : 0);
+    if (workspace_bytes < need) {
+        ymi_set_error("conv2d_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
+        return YMI_EWORKSPACE;
+    }
+    WgradArgs a{};
+    a.x = x->data; a.dy = dy->data; a.slab = reinterpret_cast<float*>(workspace); a.zero = ymi_zero_page();
+    a.ldx = x->ld; a.ldy = dy->ld;
+    a.Mpix = (int)mpix; a.H = (int)x->h; a.W = (int)x->w; a.Ho = (int)dy->h; a.Wo = (int)dy->w;
+    a.stride = (int)stride; a.pad = (int)pad; a.KW = (int)kw;
+    a.CoutP = (int)dy->c; a.Cin = (int)x->c; a.NG = (int)ng; a.pix_per_split = p.pix_per_split;
+    dim3 grid((unsigned)((ng + WG_BN - 1) / WG_BN), (unsigned)((dy->c + WG_BM - 1) / WG_BM), (unsigned)p.splits);
+    hipStream_t s = (hipStream_t)stream;
+    if (x->dtype == YMI_BF16) {
+        const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 2);
+        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), lds, s, a);
+    } else {
+        const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
+        hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, s, a);
+    }
+    YMI_CHECK_LAUNCH("wgrad");
+    const int64_t total = cout_real * kh * kw * cin_real;
+    int64_t gb = (total + 255) / 256;
+    if (gb > 2048) gb = 2048;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, (const float*)a.slab, p.splits, a.CoutP, a.NG, a.Cin,
+                       (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
+    YMI_CHECK_LAUNCH("wgrad_reduce");
+    if (dbias) {
+        // bias gradient: column sums of dy (first cout_real channels are the real ones)
+        float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.slab_bytes);
+        float* sums = part + (size_t)1024 * 2 * dy->c;
+        int rc = ymi_colsum(dy, sums, part, (size_t)1024 * 2 * dy->c * sizeof(float), stream);
+        if (rc) return rc;
+        // copy the real channels out
+        hipError_t e = hipMemcpyAsync(dbias, sums, cout_real * sizeof(float), hipMemcpyDeviceToDevice, s);
+        if (e != hipSuccess) {
+            ymi_set_error("conv2d_bwd_weight: dbias copy: %s", hipGetErrorString(e));
+            return YMI_ELAUNCH;
+        }
+    }
+    return YMI_OK;
+}

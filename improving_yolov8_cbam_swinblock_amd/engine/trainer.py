@@ -1,0 +1,69 @@
+"""Training step of the hot path (reference: ultralytics/engine/trainer.py:383-399,614-622,788-849 and
+models/yolo/detect/train.py:90-115), reduced to what the benchmark step needs: bf16 autocast forward,
+v8 detection loss, backward (+ RCCL gradient mean), gradient clip 10.0, SGD-nesterov step."""
+import torch
+import torch.nn as nn
+
+from .ddp import GradientBuckets
+
+
+def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
+    """parameter groups of reference build_optimizer (trainer.py:788-849): weights with decay, BN/LN weights and
+    all biases without; SGD with nesterov momentum (the 'SGD' branch, trainer.py:832-833)."""
+    g_w, g_n, g_b = [], [], []
+    norm = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
+    for mod_name, mod in model.named_modules():
+        for pn, p in mod.named_parameters(recurse=False):
+            if not p.requires_grad:
+                continue
+            if "bias" in pn:
+                g_b.append(p)
+            elif isinstance(mod, norm):
+                g_n.append(p)
+            else:
+                g_w.append(p)
+    opt = torch.optim.SGD(g_b, lr=lr, momentum=momentum, nesterov=True)
+    opt.add_param_group({"params": g_w, "weight_decay": decay})
+    opt.add_param_group({"params": g_n, "weight_decay": 0.0})
+    return opt
+
+
+def synthetic_batch(batch, imgsz, device, seed, boxes_per_image=4):
+    """the synthetic batch of SURVEY.md section 8(d) config 3: U[0,1) images, 4 boxes per image, class 0."""
+    g = torch.Generator().manual_seed(seed)
+    img = torch.rand(batch, 3, imgsz, imgsz, generator=g)
+    n = batch * boxes_per_image
+    ctr = torch.rand(n, 2, generator=g) * 0.6 + 0.2
+    wh = torch.rand(n, 2, generator=g) * 0.3 + 0.05
+    return {
+        "img": img.to(device),
+        "batch_idx": torch.arange(batch).repeat_interleave(boxes_per_image).float().to(device),
+        "cls": torch.zeros(n, 1, device=device),
+        "bboxes": torch.cat((ctr, wh), 1).to(device),
+        "max_boxes": boxes_per_image,
+    }
+
+
+class TrainStep:
+    """one optimisation step: forward under autocast, loss.sum() * world (reference trainer.py:386-388), backward
+    with bucketed RCCL mean, unscale-free clip (bf16 needs no GradScaler), optimizer step, zero_grad."""
+
+    def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20):
+        self.model = model
+        self.world = world_size
+        self.dtype = dtype
+        self.opt = build_optimizer(model, lr=lr)
+        self.buckets = GradientBuckets(model, world_size, bucket_bytes)
+        self.params = [p for p in model.parameters() if p.requires_grad]
+
+    def __call__(self, batch):
+        self.model.train()
+        with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
+            loss, items = self.model(batch)
+            total = loss.sum() * self.world
+        total.backward()
+        self.buckets.finish()
+        torch.nn.utils.clip_grad_norm_(self.params, max_norm=10.0)
+        self.opt.step()
+        self.opt.zero_grad(set_to_none=True)
+        return items

@@ -1,0 +1,77 @@
+"""Bottleneck / C2f / SPPF / DFL (reference: ultralytics/nn/modules/block.py)."""
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .conv import Conv
+
+
+class DFL(nn.Module):
+    """expectation over the 16-bin box distribution (reference block.py:58-77); frozen weights 0..15.
+    Inference-side decode on [B, 4*c1, A] tensors: tiny, stays in torch ops."""
+
+    def __init__(self, c1=16):
+        super().__init__()
+        self.conv = nn.Conv2d(c1, 1, 1, bias=False).requires_grad_(False)
+        self.conv.weight.data[:] = torch.arange(c1, dtype=torch.float).view(1, c1, 1, 1)
+        self.c1 = c1
+
+    def forward(self, x):
+        b, _, a = x.shape
+        p = x.view(b, 4, self.c1, a).float().softmax(2)
+        return (p * self.conv.weight.view(1, 1, self.c1, 1).float()).sum(2)
+
+
+class Bottleneck(nn.Module):
+    """x + cv2(cv1(x)) when shortcut and c1 == c2 (reference block.py:479-488); the add rides in
+    cv2's BN/SiLU kernel."""
+
+    def __init__(self, c1, c2, shortcut=True, g=1, k=(3, 3), e=0.5):
+        super().__init__()
+        c_ = int(c2 * e)
+        self.cv1 = Conv(c1, c_, k[0], 1)
+        self.cv2 = Conv(c_, c2, k[1], 1, g=g)
+        self.add = shortcut and c1 == c2
+
+    def forward(self, x):
+        x = ops.to_internal(x)
+        return self.cv2(self.cv1(x), residual=x if self.add else None)
+
+
+class C2f(nn.Module):
+    """cv1 -> 2 chunks -> n chained Bottlenecks -> concat -> cv2 (reference block.py:279-304).
+    The chunks are channel slices of cv1's NHWC output (no copy)."""
+
+    def __init__(self, c1, c2, n=1, shortcut=False, g=1, e=0.5):
+        super().__init__()
+        self.c = int(c2 * e)
+        self.cv1 = Conv(c1, 2 * self.c, 1, 1)
+        self.cv2 = Conv((2 + n) * self.c, c2, 1)
+        self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
+
+    def forward(self, x):
+        t = self.cv1(x)
+        ys = [t]  # both chunks at once: they are adjacent in memory
+        last = t[:, self.c :]
+        for m in self.m:
+            last = m(last)
+            ys.append(last)
+        return self.cv2(ops.concat(ys))
+
+    forward_split = forward
+
+
+class SPPF(nn.Module):
+    """cv1 -> three chained k x k max-pools -> concat(4) -> cv2 (reference block.py:201-226); the
+    pools and the concat are one LDS-staged kernel (csrc/pool.hip)."""
+
+    def __init__(self, c1, c2, k=5):
+        super().__init__()
+        c_ = c1 // 2
+        self.cv1 = Conv(c1, c_, 1, 1)
+        self.cv2 = Conv(c_ * 4, c2, 1, 1)
+        self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)  # attribute kept for parity with the reference
+
+    def forward(self, x):
+        y0 = self.cv1(x)
+        return self.cv2(ops.sppf_pool_cat(y0, self.m.kernel_size))

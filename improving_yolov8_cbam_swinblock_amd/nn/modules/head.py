@@ -1,0 +1,94 @@
+"""Detect head (reference: ultralytics/nn/modules/head.py:23-183), legacy (v8) class branch."""
+import math
+
+import torch
+import torch.nn as nn
+
+from ... import ops
+from .block import DFL
+from .conv import Conv
+
+
+def make_anchors(feats, strides, grid_cell_offset=0.5):
+    """anchor centres and strides per level (reference utils/tal.py:364-376)."""
+    pts, st = [], []
+    dtype, device = torch.float32, feats[0].device
+    for f, s in zip(feats, strides):
+        h, w = f.shape[2:]
+        sx = torch.arange(w, device=device, dtype=dtype) + grid_cell_offset
+        sy = torch.arange(h, device=device, dtype=dtype) + grid_cell_offset
+        gy, gx = torch.meshgrid(sy, sx, indexing="ij")
+        pts.append(torch.stack((gx, gy), -1).view(-1, 2))
+        st.append(torch.full((h * w, 1), float(s), dtype=dtype, device=device))
+    return torch.cat(pts), torch.cat(st)
+
+
+def dist2bbox(distance, anchor_points, xywh=True, dim=-1):
+    """reference utils/tal.py:379-388."""
+    lt, rb = distance.chunk(2, dim)
+    x1y1, x2y2 = anchor_points - lt, anchor_points + rb
+    if xywh:
+        return torch.cat(((x1y1 + x2y2) / 2, x2y2 - x1y1), dim)
+    return torch.cat((x1y1, x2y2), dim)
+
+
+class _Out1x1(nn.Conv2d):
+    """Detect's biased 1x1 output conv: an nn.Conv2d (same state-dict keys) whose forward is the MFMA kernel."""
+
+    def forward(self, x):
+        return ops.conv_affine_act(ops.to_internal(x), self.weight, None, self.bias, 1, ops.ACT_NONE, None, pad_out=True)
+
+
+class Detect(nn.Module):
+    """per level: cat(cv2[i](x), cv3[i](x)); train -> list of [B, 4*16+nc, H, W]; eval -> (decoded, list)."""
+
+    dynamic = False
+    export = False
+    format = None
+    end2end = False
+    max_det = 300
+    shape = None
+    anchors = torch.empty(0)
+    strides = torch.empty(0)
+    legacy = True  # parse_model sets True for v8 YAMLs (reference tasks.py:1355,1488); only that branch is built
+
+    def __init__(self, nc=80, ch=()):
+        super().__init__()
+        if not self.legacy:
+            raise NotImplementedError("only the legacy (YOLOv8) class branch of Detect is on the hot path")
+        self.nc = nc
+        self.nl = len(ch)
+        self.reg_max = 16
+        self.no = nc + self.reg_max * 4
+        self.stride = torch.zeros(self.nl)
+        c2, c3 = max((16, ch[0] // 4, self.reg_max * 4)), max(ch[0], min(self.nc, 100))
+        self.cv2 = nn.ModuleList(nn.Sequential(Conv(x, c2, 3), Conv(c2, c2, 3), _Out1x1(c2, 4 * self.reg_max, 1)) for x in ch)
+        self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), _Out1x1(c3, self.nc, 1)) for x in ch)
+        self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
+
+    def forward(self, x):
+        x = list(x)
+        for i in range(self.nl):
+            xi = ops.to_internal(x[i])
+            x[i] = ops.concat([self.cv2[i](xi), self.cv3[i](xi)])
+        if self.training:
+            return x
+        y = self._inference(x)
+        return y if self.export else (y, x)
+
+    def _inference(self, x):
+        """reference head.py:103-142, non-export branch (decode of [B, no, 8400]: small torch ops)."""
+        shape = x[0].shape
+        x_cat = torch.cat([xi.float().reshape(shape[0], self.no, -1) for xi in x], 2)
+        if self.dynamic or self.shape != shape:
+            self.anchors, self.strides = (t.transpose(0, 1) for t in make_anchors(x, self.stride, 0.5))
+            self.shape = shape
+        box, cls = x_cat.split((self.reg_max * 4, self.nc), 1)
+        dbox = dist2bbox(self.dfl(box), self.anchors.unsqueeze(0), xywh=True, dim=1) * self.strides
+        return torch.cat((dbox, cls.sigmoid()), 1)
+
+    def bias_init(self):
+        """reference head.py:144-155."""
+        for a, b, s in zip(self.cv2, self.cv3, self.stride):
+            a[-1].bias.data[:] = 1.0
+            b[-1].bias.data[: self.nc] = math.log(5 / self.nc / (640 / s) ** 2)

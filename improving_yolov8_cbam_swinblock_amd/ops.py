@@ -1,0 +1,582 @@
+"""torch.autograd.Function wrappers over the C ABI of libyolo_mi355.so.
+
+PyTorch is plumbing here: it owns device memory, streams and the autograd tape; every tensor
+operation on the hot path is a hand-written gfx950 kernel reached through `_lib` (ctypes).  There is
+no fallback: without the library, or with CPU tensors, these functions raise.
+
+Tensor convention between ops: logical [N, C, H, W] tensors whose MEMORY is NHWC (channels_last),
+possibly a channel slice of a wider buffer (pixel stride ld > C); token matrices are plain [T, C].
+Compute dtype is bfloat16 under `torch.autocast("cuda", dtype=torch.bfloat16)` and the input's
+dtype (float32 = parity mode) otherwise; parameters stay float32 and are packed per call.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, as_ymi, check, chunk_elems, empty_nhwc, is_nhwc, ptr, stream_ptr, workspace, ymi_dtype
+
+_byref = ctypes.byref
+
+
+def L():
+    return _lib.lib()
+
+
+def compute_dtype(x):
+    if torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False:
+        dt = torch.get_autocast_dtype("cuda")
+        if dt != torch.bfloat16:
+            raise RuntimeError(f"libyolo_mi355 supports bfloat16 autocast only (got {dt}); fp16 has no kernels here")
+        return dt
+    return x.dtype if x.dtype in (torch.float32, torch.bfloat16) else torch.float32
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+def _dense_ok(t, dtype):
+    ch = chunk_elems(dtype)
+    if t.dtype != dtype or not is_nhwc(t):
+        return False
+    n, c, h, w = t.shape
+    ld = as_ymi(t).ld
+    return c % ch == 0 and ld % ch == 0 and t.data_ptr() % 16 == 0
+
+
+class _ToInternal(torch.autograd.Function):
+    """NCHW float32 (the reference's API format) -> NHWC compute dtype, channels zero-padded to a
+    16-byte multiple.  API edge of the model (first Conv input)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        n, c, h, w = x.shape
+        cp = round_up(c, chunk_elems(dtype))
+        src = x.detach()
+        if src.dtype != torch.float32 or not src.is_contiguous():
+            src = src.float().contiguous()
+        out = empty_nhwc(n, cp, h, w, dtype, x.device)
+        check(L().ymi_nchw_to_nhwc(ptr(src), n, c, h, w, _byref(as_ymi(out)), stream_ptr()), "nchw_to_nhwc")
+        ctx.c = c
+        ctx.in_dtype = x.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = grad_nhwc(g, g.dtype if g.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        n, cp, h, w = g.shape
+        full = torch.empty((n, cp, h, w), dtype=torch.float32, device=g.device)
+        check(L().ymi_nhwc_to_nchw(_byref(as_ymi(g)), ptr(full), stream_ptr()), "nhwc_to_nchw")
+        return full[:, : ctx.c].to(ctx.in_dtype), None
+
+
+def to_internal(x, dtype=None):
+    dtype = dtype or compute_dtype(x)
+    if not x.is_cuda:
+        raise RuntimeError("improving_yolov8_cbam_swinblock_amd runs on the MI355X only: move the input to 'cuda' (no CPU path)")
+    if _dense_ok(x, dtype):
+        return x
+    return _ToInternal.apply(x, dtype)
+
+
+def grad_nhwc(g, dtype):
+    """normalise an incoming gradient to dense NHWC memory of `dtype` (torch-side plumbing)."""
+    if g.dtype != dtype:
+        g = g.to(dtype)
+    if g.dim() == 4:
+        if not _dense_ok(g, dtype):
+            n, c, h, w = g.shape
+            buf = empty_nhwc(n, c, h, w, dtype, g.device)
+            buf.copy_(g)
+            g = buf
+    elif g.dim() == 2:
+        if g.stride(1) != 1 or g.stride(0) % 4 != 0 or g.data_ptr() % 16 != 0:
+            g = g.contiguous()
+    return g
+
+
+def to_nchw_float(x):
+    """NHWC compute-dtype tensor -> contiguous NCHW float32 (for callers that need the reference format)."""
+    n, c, h, w = x.shape
+    out = torch.empty((n, c, h, w), dtype=torch.float32, device=x.device)
+    check(L().ymi_nhwc_to_nchw(_byref(as_ymi(x.detach())), ptr(out), stream_ptr()), "nhwc_to_nchw")
+    return out
+
+
+# ------------------------------------------------------------------------------------ weights
+def pack_conv_fwd(weight, cin_pad, dtype):
+    o, i, kh, kw = weight.shape
+    buf = torch.empty(o * kh * kw * cin_pad, dtype=dtype, device=weight.device)
+    check(L().ymi_pack_conv_weight_fwd(ptr(weight.detach()), o, i, kh, kw, cin_pad, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_fwd")
+    return buf
+
+
+def pack_conv_dgrad(weight, cout_pad, stride, dtype):
+    o, i, kh, kw = weight.shape
+    buf = torch.empty(cout_pad * i * kh * kw, dtype=dtype, device=weight.device)
+    check(L().ymi_pack_conv_weight_dgrad_ex(ptr(weight.detach()), o, cout_pad, i, kh, kw, stride, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_dgrad")
+    return buf
+
+
+def _as4d(w):
+    return w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
+
+
+def _conv_out_hw(h, w, k, s):
+    p = k // 2
+    return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
+
+
+def _wgrad(x, dy, cout, cin, k, stride, want_bias):
+    """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None)"""
+    dev = x.device
+    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
+    db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+    ty, tx = as_ymi(dy), as_ymi(x)
+    need = L().ymi_conv2d_bwd_weight_workspace(ty.n * ty.h * ty.w, ty.c, tx.c, k, k)
+    ws = workspace(need, dev, "wgrad")
+    check(L().ymi_conv2d_bwd_weight(_byref(tx), _byref(ty), cout, cin, k, k, stride, ptr(dw), ptr(db), ptr(ws), ws.numel(), stream_ptr()), "conv2d_bwd_weight")
+    return dw, db
+
+
+def _dgrad(dy, weight4, cin_out, k, stride, in_shape, dtype):
+    """dx [N, cin_out, H, W] (NHWC) from dy and the OIHW weight."""
+    n, _, h, w = in_shape
+    ty = as_ymi(dy)
+    wd = pack_conv_dgrad(weight4, ty.c, stride, dtype)
+    if len(in_shape) == 4:
+        dx = empty_nhwc(n, cin_out, h, w, dtype, dy.device)
+    check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), cin_out, k, k, stride, _byref(as_ymi(dx)), stream_ptr()), "conv2d_bwd_data")
+    return dx
+
+
+# ------------------------------------------------------------------- Conv + BN(train) + act
+class _ConvBnAct(torch.autograd.Function):
+    """act(BatchNorm_train(conv(x))) (+ residual).  Reference: Conv.forward, nn/modules/conv.py:69-79
+    (+ Bottleneck add, nn/modules/block.py:488)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum, act, residual):
+        dtype = x.dtype
+        o, i, k, _ = weight.shape
+        n, cp, h, w = x.shape
+        ho, wo = _conv_out_hw(h, w, k, stride)
+        dev = x.device
+        wp = pack_conv_fwd(weight, cp, dtype)
+        raw = empty_nhwc(n, o, ho, wo, dtype, dev)
+        out = empty_nhwc(n, o, ho, wo, dtype, dev)
+        stats = torch.empty((2, o), dtype=torch.float32, device=dev)
+        m = n * ho * wo
+        need = (L().ymi_conv2d_stat_blocks(m, o) * 2 * o + 2 * o) * 4
+        ws = workspace(need, dev, "conv")
+        res = residual
+        check(
+            L().ymi_conv2d_bn_silu_fwd(
+                _byref(as_ymi(x)), ptr(wp), o, k, k, stride, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                momentum, eps, act, _byref(as_ymi(res)) if res is not None else None, _byref(as_ymi(raw)), _byref(as_ymi(out)),
+                ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream_ptr(),
+            ),
+            "conv2d_bn_silu_fwd",
+        )
+        ctx.save_for_backward(x, weight, gamma, beta, raw, stats)
+        ctx.cfg = (stride, act, i, residual is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, gamma, beta, raw, stats = ctx.saved_tensors
+        stride, act, cin, has_res = ctx.cfg
+        dtype = x.dtype
+        o, _, k, _ = weight.shape
+        dev = x.device
+        dout = grad_nhwc(dout, dtype)
+        draw = empty_nhwc(*raw.shape, dtype, dev)
+        dgb = torch.empty((2, o), dtype=torch.float32, device=dev)
+        ws = workspace(1024 * 2 * o * 4 + 256, dev, "bnbwd")
+        check(
+            L().ymi_bn_act_bwd(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(beta), act,
+                               _byref(as_ymi(draw)), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), ws.numel(), stream_ptr()),
+            "bn_act_bwd",
+        )
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = _dgrad(draw, weight, x.shape[1], k, stride, x.shape, dtype)
+        dw, _ = _wgrad(x, draw, o, cin, k, stride, False)
+        dres = dout if (has_res and ctx.needs_input_grad[10]) else None
+        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, dres
+
+
+def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None):
+    """train-mode Conv block on an internal (NHWC) tensor; updates bn.running_* in place."""
+    if bn.momentum is None:
+        raise RuntimeError("BatchNorm with cumulative moving average (momentum=None) is not supported")
+    out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual)
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return out
+
+
+# ------------------------------------------------------------------- conv / linear with affine epilogue
+class _ConvAffineAct(torch.autograd.Function):
+    """y = act(scale*conv(x) + bias) (+ residual), one kernel.  Used for eval-mode Conv (BN folded into
+    scale/bias: conv.py:81-91 and utils/torch_utils.py:240-271), Detect's biased 1x1 outputs
+    (head.py:45-59) and every nn.Linear of SwinBlock (swin_block.py:29-35) with k = 1."""
+
+    @staticmethod
+    def forward(ctx, x, weight, scale, bias, stride, act, residual, cout_pad):
+        dtype = x.dtype
+        w4 = _as4d(weight)
+        o, i, k, _ = w4.shape
+        dev = x.device
+        wp = pack_conv_fwd(w4, x.shape[1], dtype)
+        if x.dim() == 4:
+            n, cp, h, w = x.shape
+            ho, wo = _conv_out_hw(h, w, k, stride)
+            y = empty_nhwc(n, cout_pad, ho, wo, dtype, dev)
+            yv = y[:, :o] if cout_pad != o else y
+            if cout_pad != o:
+                y.zero_()
+        else:
+            y = torch.empty((x.shape[0], cout_pad), dtype=dtype, device=dev)
+            yv = y[:, :o] if cout_pad != o else y
+            if cout_pad != o:
+                y.zero_()
+        check(
+            L().ymi_conv2d_fwd(_byref(as_ymi(x)), ptr(wp), o, k, k, stride, ptr(scale), ptr(bias), act,
+                               _byref(as_ymi(residual)) if residual is not None else None, _byref(as_ymi(yv)), None, None, stream_ptr()),
+            "conv2d_fwd",
+        )
+        if act != ACT_NONE or scale is not None:
+            ctx.unsupported = "backward through a fused activation / BN-folded conv is not implemented (use train mode or act=none)"
+        else:
+            ctx.unsupported = None
+        ctx.save_for_backward(x, weight)
+        ctx.cfg = (stride, i, bias is not None, residual is not None, cout_pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.unsupported:
+            raise NotImplementedError(ctx.unsupported)
+        x, weight = ctx.saved_tensors
+        stride, cin, has_bias, has_res, cout_pad = ctx.cfg
+        dtype = x.dtype
+        w4 = _as4d(weight)
+        o, _, k, _ = w4.shape
+        dy = grad_nhwc(dy, dtype)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if x.dim() == 4:
+                dx = _dgrad(dy, w4, x.shape[1], k, stride, x.shape, dtype)
+            else:
+                ty = as_ymi(dy)
+                wd = pack_conv_dgrad(w4, ty.c, 1, dtype)
+                dx = torch.empty((x.shape[0], x.shape[1]), dtype=dtype, device=x.device)
+                check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), x.shape[1], 1, 1, 1, _byref(as_ymi(dx)), stream_ptr()), "conv2d_bwd_data")
+        dw, db = _wgrad(x, dy, o, cin, k, stride, has_bias)
+        dw = dw.view(weight.shape)
+        dres = None
+        if has_res and ctx.needs_input_grad[6]:
+            dres = dy[:, :o] if cout_pad != o else dy
+        return dx, dw, None, db, None, None, dres, None
+
+
+def conv_affine_act(x, weight, scale=None, bias=None, stride=1, act=ACT_NONE, residual=None, pad_out=False):
+    w4 = _as4d(weight)
+    o = w4.shape[0]
+    cout_pad = round_up(o, chunk_elems(x.dtype)) if pad_out else o
+    y = _ConvAffineAct.apply(x, weight, scale, bias, int(stride), int(act), residual, cout_pad)
+    if cout_pad != o:
+        y = y[:, :o]
+    return y
+
+
+def linear(x, weight, bias=None, residual=None):
+    """token GEMM: x [T, Cin] @ weight[Cout, Cin]^T + bias (+ residual)."""
+    return _ConvAffineAct.apply(x, weight, None, bias, 1, ACT_NONE, residual, weight.shape[0])
+
+
+class _Act(torch.autograd.Function):
+    """elementwise activation on a token matrix (exact-erf GELU of swin_block.py:33)."""
+
+    @staticmethod
+    def forward(ctx, pre, act):
+        out = torch.empty_like(pre)
+        check(L().ymi_scale_shift_act(_byref(as_ymi(pre)), None, None, act, None, _byref(as_ymi(out)), stream_ptr()), "scale_shift_act")
+        ctx.save_for_backward(pre)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (pre,) = ctx.saved_tensors
+        if ctx.act != ACT_GELU:
+            raise NotImplementedError("only GELU has a stand-alone backward")
+        dy = grad_nhwc(dy, pre.dtype)
+        dx = torch.empty_like(pre)
+        check(L().ymi_gelu_bwd(_byref(as_ymi(pre)), _byref(as_ymi(dy)), _byref(as_ymi(dx)), stream_ptr()), "gelu_bwd")
+        return dx, None
+
+
+def gelu(pre):
+    return _Act.apply(pre, ACT_GELU)
+
+
+# ------------------------------------------------------------------------ concat / upsample
+class _Concat(torch.autograd.Function):
+    """channel concat by strided copies into one NHWC buffer (conv.py:683, block.py:226,304)."""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        n, _, h, w = xs[0].shape
+        cs = [t.shape[1] for t in xs]
+        out = empty_nhwc(n, sum(cs), h, w, xs[0].dtype, xs[0].device)
+        off = 0
+        for t, c in zip(xs, cs):
+            check(L().ymi_copy(_byref(as_ymi(t)), _byref(as_ymi(out[:, off : off + c])), stream_ptr()), "copy")
+            off += c
+        ctx.cs = cs
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        outs, off = [], 0
+        for c in ctx.cs:
+            outs.append(g[:, off : off + c])
+            off += c
+        return tuple(outs)
+
+
+def concat(xs):
+    return _Concat.apply(*xs)
+
+
+class _Upsample2x(torch.autograd.Function):
+    """nn.Upsample(None, 2, 'nearest') (yolov8.yaml:759,764) and its adjoint (2x2 block sums)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        n, c, h, w = x.shape
+        out = empty_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
+        check(L().ymi_upsample2x(_byref(as_ymi(x)), _byref(as_ymi(out)), stream_ptr()), "upsample2x")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = grad_nhwc(g, g.dtype)
+        n, c, h, w = g.shape
+        dx = empty_nhwc(n, c, h // 2, w // 2, g.dtype, g.device)
+        check(L().ymi_upsample2x_bwd(_byref(as_ymi(g)), _byref(as_ymi(dx)), stream_ptr()), "upsample2x_bwd")
+        return dx
+
+
+def upsample2x(x):
+    return _Upsample2x.apply(x)
+
+
+# ----------------------------------------------------------------------------------- SPPF pools
+class _SppfPool(torch.autograd.Function):
+    """cat[y0, mp(y0), mp(mp(y0)), mp(mp(mp(y0)))] in one buffer: block.py:222-226."""
+
+    @staticmethod
+    def forward(ctx, y0, k):
+        n, c, h, w = y0.shape
+        cat = empty_nhwc(n, 4 * c, h, w, y0.dtype, y0.device)
+        sl = [cat[:, i * c : (i + 1) * c] for i in range(4)]
+        check(L().ymi_copy(_byref(as_ymi(y0)), _byref(as_ymi(sl[0])), stream_ptr()), "copy")
+        check(L().ymi_sppf_pool3_fwd(_byref(as_ymi(y0)), k, _byref(as_ymi(sl[1])), _byref(as_ymi(sl[2])), _byref(as_ymi(sl[3])), stream_ptr()), "sppf_pool3_fwd")
+        ctx.save_for_backward(cat)
+        ctx.k, ctx.c = k, c
+        return cat
+
+    @staticmethod
+    def backward(ctx, g):
+        (cat,) = ctx.saved_tensors
+        c, k = ctx.c, ctx.k
+        n, _, h, w = cat.shape
+        work = empty_nhwc(n, 4 * c, h, w, cat.dtype, cat.device)
+        work.copy_(g)  # private copy: the routing below accumulates in place
+        y = [cat[:, i * c : (i + 1) * c] for i in range(3)]
+        d = [work[:, i * c : (i + 1) * c] for i in range(4)]
+        check(
+            L().ymi_sppf_pool3_bwd(_byref(as_ymi(y[0])), _byref(as_ymi(y[1])), _byref(as_ymi(y[2])), k, _byref(as_ymi(d[1])),
+                                   _byref(as_ymi(d[2])), _byref(as_ymi(d[3])), _byref(as_ymi(d[0])), stream_ptr()),
+            "sppf_pool3_bwd",
+        )
+        return d[0], None
+
+
+def sppf_pool_cat(y0, k):
+    return _SppfPool.apply(y0, int(k))
+
+
+# ----------------------------------------------------------------------------------------- CBAM
+class _Cbam(torch.autograd.Function):
+    """cbam.py:62-71 (channel attention :29-38, spatial attention :48-53)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, w2, wsa):
+        n, c, h, w = x.shape
+        hidden = w1.shape[0]
+        ksa = wsa.shape[-1]
+        dev = x.device
+        out = empty_nhwc(n, c, h, w, x.dtype, dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        ca = torch.empty((n, c), **f32)
+        pooled = torch.empty((n, 2, c), **f32)
+        pool_arg = torch.empty((n, c), **i32)
+        smap = torch.empty((n, h, w, 2), **f32)
+        smap_arg = torch.empty((n, h, w), **i32)
+        sa = torch.empty((n, h, w), **f32)
+        w1c, w2c, wsc = w1.detach().reshape(hidden, c).contiguous(), w2.detach().reshape(c, hidden).contiguous(), wsa.detach().reshape(2, ksa, ksa).contiguous()
+        check(
+            L().ymi_cbam_fwd(_byref(as_ymi(x)), ptr(w1c), ptr(w2c), hidden, ptr(wsc), ksa, _byref(as_ymi(out)), ptr(ca), ptr(pooled), ptr(pool_arg),
+                             ptr(smap), ptr(smap_arg), ptr(sa), stream_ptr()),
+            "cbam_fwd",
+        )
+        ctx.save_for_backward(x, w1, w2, wsa, ca, pooled, pool_arg, smap, smap_arg, sa)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w1, w2, wsa, ca, pooled, pool_arg, smap, smap_arg, sa = ctx.saved_tensors
+        n, c, h, w = x.shape
+        hidden, ksa = w1.shape[0], wsa.shape[-1]
+        dev = x.device
+        g = grad_nhwc(g, x.dtype)
+        dx = empty_nhwc(n, c, h, w, x.dtype, dev)
+        dw1 = torch.empty((hidden, c), dtype=torch.float32, device=dev)
+        dw2 = torch.empty((c, hidden), dtype=torch.float32, device=dev)
+        dwsa = torch.empty((2, ksa, ksa), dtype=torch.float32, device=dev)
+        w1c, w2c, wsc = w1.detach().reshape(hidden, c).contiguous(), w2.detach().reshape(c, hidden).contiguous(), wsa.detach().reshape(2, ksa, ksa).contiguous()
+        ws = workspace(L().ymi_cbam_bwd_workspace(n, h, w, c, hidden), dev, "cbam")
+        check(
+            L().ymi_cbam_bwd(_byref(as_ymi(x)), _byref(as_ymi(g)), ptr(w1c), ptr(w2c), hidden, ptr(wsc), ksa, ptr(ca), ptr(pooled), ptr(pool_arg),
+                             ptr(smap), ptr(smap_arg), ptr(sa), _byref(as_ymi(dx)), ptr(dw1), ptr(dw2), ptr(dwsa), ptr(ws), ws.numel(), stream_ptr()),
+            "cbam_bwd",
+        )
+        return dx, dw1.view(w1.shape), dw2.view(w2.shape), dwsa.view(wsa.shape)
+
+
+def cbam(x, w1, w2, wsa):
+    return _Cbam.apply(x, w1, w2, wsa)
+
+
+# ----------------------------------------------------------------------------------- SwinBlock
+def window_pad(h, w, ws):
+    return round_up(h, ws), round_up(w, ws)
+
+
+class _LayerNorm(torch.autograd.Function):
+    """LayerNorm over channels.  ws > 0: x is the NHWC image and rows are gathered through the window map
+    (pad + rearrange + window_partition + norm1, swin_block.py:41-50); ws == 0: x is a token matrix (norm2)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, ws):
+        dev = x.device
+        if ws > 0:
+            n, c, h, w = x.shape
+            hp, wp = window_pad(h, w, ws)
+            t = n * hp * wp
+        else:
+            t, c = x.shape
+        out = torch.empty((t, c), dtype=x.dtype, device=dev)
+        stats = torch.empty((2, t), dtype=torch.float32, device=dev)
+        check(L().ymi_layernorm_fwd(_byref(as_ymi(x)), ws, ptr(gamma), ptr(beta), eps, _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), stream_ptr()), "layernorm_fwd")
+        ctx.save_for_backward(x, gamma, stats)
+        ctx.ws = ws
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, gamma, stats = ctx.saved_tensors
+        ws = ctx.ws
+        dev = x.device
+        g = grad_nhwc(g, x.dtype)
+        c = x.shape[1]
+        dx = empty_nhwc(*x.shape, x.dtype, dev) if ws > 0 else torch.empty_like(x)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        wsb = workspace(512 * 2 * c * 4 + 256, dev, "ln")
+        check(
+            L().ymi_layernorm_bwd(_byref(as_ymi(x)), ws, _byref(as_ymi(g)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), _byref(as_ymi(dx)), 0,
+                                  ptr(dgb[0]), ptr(dgb[1]), ptr(wsb), wsb.numel(), stream_ptr()),
+            "layernorm_bwd",
+        )
+        return dx, dgb[0], dgb[1], None, None
+
+
+def layernorm(x, ln, ws=0):
+    return _LayerNorm.apply(x, ln.weight, ln.bias, float(ln.eps), int(ws))
+
+
+class _WindowAttention(torch.autograd.Function):
+    """softmax(q k^T / sqrt(hd)) v per (window, head) on packed qkv tokens: the core of
+    nn.MultiheadAttention as called at swin_block.py:51 (no mask: pad tokens are ordinary keys)."""
+
+    @staticmethod
+    def forward(ctx, qkv, wlen, heads):
+        t, c3 = qkv.shape
+        c = c3 // 3
+        out = torch.empty((t, c), dtype=qkv.dtype, device=qkv.device)
+        lse = torch.empty((t, heads), dtype=torch.float32, device=qkv.device)
+        check(L().ymi_window_attention_fwd(_byref(as_ymi(qkv)), wlen, heads, _byref(as_ymi(out)), ptr(lse), stream_ptr()), "window_attention_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.cfg = (wlen, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        qkv, out, lse = ctx.saved_tensors
+        wlen, heads = ctx.cfg
+        g = grad_nhwc(g, qkv.dtype)
+        dqkv = torch.empty_like(qkv)
+        check(
+            L().ymi_window_attention_bwd(_byref(as_ymi(qkv)), _byref(as_ymi(out)), _byref(as_ymi(g)), ptr(lse), wlen, heads, _byref(as_ymi(dqkv)), stream_ptr()),
+            "window_attention_bwd",
+        )
+        return dqkv, None, None
+
+
+def window_attention(qkv, wlen, heads):
+    return _WindowAttention.apply(qkv, int(wlen), int(heads))
+
+
+class _WindowReverse(torch.autograd.Function):
+    """tokens -> NHWC image with the padding cropped (window_reverse + rearrange + crop, swin_block.py:55-58)."""
+
+    @staticmethod
+    def forward(ctx, tokens, n, h, w, ws):
+        c = tokens.shape[1]
+        out = empty_nhwc(n, c, h, w, tokens.dtype, tokens.device)
+        check(L().ymi_window_reverse(_byref(as_ymi(tokens)), ws, _byref(as_ymi(out)), stream_ptr()), "window_reverse")
+        ctx.cfg = (ws, tokens.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        ws, t = ctx.cfg
+        g = grad_nhwc(g, g.dtype)
+        d = torch.empty((t, g.shape[1]), dtype=g.dtype, device=g.device)
+        check(L().ymi_window_partition(_byref(as_ymi(g)), ws, _byref(as_ymi(d)), stream_ptr()), "window_partition")
+        return d, None, None, None, None
+
+
+def window_reverse(tokens, n, h, w, ws):
+    return _WindowReverse.apply(tokens, int(n), int(h), int(w), int(ws))
+
+
+def window_partition_index(n, hp, wp, ws, device):
+    idx = torch.empty(n * hp * wp, dtype=torch.int32, device=device)
+    check(L().ymi_window_partition_index(n, hp, wp, ws, ptr(idx), stream_ptr()), "window_partition_index")
+    return idx
+
+
+def window_partition(x, ws):
+    """stand-alone copy form (tests): NHWC image -> [T, C] tokens with zero padding."""
+    n, c, h, w = x.shape
+    hp, wp = window_pad(h, w, ws)
+    out = torch.empty((n * hp * wp, c), dtype=x.dtype, device=x.device)
+    check(L().ymi_window_partition(_byref(as_ymi(x)), ws, _byref(as_ymi(out)), stream_ptr()), "window_partition")
+    return out

@@ -1,0 +1,194 @@
+/*
+ * ymi.h - C ABI of libyolo_mi355.so: hand-written gfx950 (MI355X / CDNA4) kernels for the
+ * YOLOv8-CBAM-Swin forward/backward hot path.
+ *
+ * The reference (mazouziwissem/improving_yolov8_CBAM_SwinBlock, a fork of Ultralytics 8.3.108) has no
+ * native kernels: its operator modules call torch.nn.functional, i.e. ATen.  Each entry point below
+ * therefore cites the reference *call site* whose ATen work it replaces (paths relative to the
+ * reference's ultralytics/ directory).  The Python-side binding is
+ * improving_yolov8_cbam_swinblock_amd/_lib.py (ctypes); INTEGRATION.md shows the stub a maintainer
+ * of the reference would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; all pointers are DEVICE pointers unless named host_*;
+ *  - activations are NHWC ("channels last"): element (n,h,w,c) of a ymi_tensor lives at
+ *    data[((n*h_dim + h)*w_dim + w)*ld + c]; ld >= c lets a tensor be a channel slice of a wider
+ *    buffer (this is how chunk/concat cost nothing);
+ *  - dtype of activations: YMI_F32 (parity mode, exact-f32 MFMA) or YMI_BF16 (fast mode, bf16 MFMA
+ *    with f32 accumulation); per-channel vectors (bias, BN affine, statistics) are always f32;
+ *  - trainable weights cross the ABI in the reference's own layouts (conv OIHW f32, linear [out,in]
+ *    f32); ymi_pack_* turn them into the kernels' K-contiguous operand layouts;
+ *  - every call only ENQUEUES work on `stream` (a hipStream_t passed as void*); nothing allocates,
+ *    frees or synchronises, so calls are graph-capturable; workspaces are caller-provided;
+ *  - return 0 on success, a negative YMI_E* otherwise; ymi_last_error() gives thread-local text.
+ */
+#ifndef YMI_H
+#define YMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define YMI_VERSION 1
+
+enum { YMI_F32 = 0, YMI_BF16 = 1 };
+enum { YMI_ACT_NONE = 0, YMI_ACT_SILU = 1, YMI_ACT_GELU = 2 };
+enum { YMI_OK = 0, YMI_EINVAL = -1, YMI_EALIGN = -2, YMI_ELAUNCH = -3, YMI_EWORKSPACE = -4 };
+
+typedef struct ymi_tensor {
+    void* data;
+    int64_t n, h, w, c;
+    int64_t ld;    /* elements between consecutive pixels, >= c */
+    int32_t dtype; /* YMI_F32 | YMI_BF16 */
+    int32_t _pad;
+} ymi_tensor;
+
+int ymi_version(void);
+const char* ymi_last_error(void);
+
+/* ---------------------------------------------------------------- layout / data movement ---- */
+
+/* NCHW f32 image -> NHWC (dst.dtype), channels c..dst.c-1 zero-filled.  Replaces the implicit
+ * layout of the first conv's input: nn/tasks.py:171 feeding nn/modules/conv.py:79. */
+int ymi_nchw_to_nhwc(const float* src, int64_t n, int64_t c, int64_t h, int64_t w, const ymi_tensor* dst, void* stream);
+/* NHWC (any dtype) -> NCHW f32.  API edge for callers that want the reference's memory format. */
+int ymi_nhwc_to_nchw(const ymi_tensor* src, float* dst, void* stream);
+/* dst[n,h,w,0:c] = src (dtype may differ: cast).  torch.cat of nn/modules/conv.py:683 and
+ * nn/modules/block.py:226,304 when the producer could not write into the slice itself. */
+int ymi_copy(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
+/* dst[n,2h+i,2w+j,:] = src[n,h,w,:] : nn.Upsample(None, 2, "nearest"), cfg yolov8.yaml:759,764. */
+int ymi_upsample2x(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
+/* adjoint: dst[n,h,w,:] = sum of the 2x2 block of src. */
+int ymi_upsample2x_bwd(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
+/* dst += src (f32 accumulate, elementwise over NHWC tensors of equal shape). */
+int ymi_add_inplace(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
+
+/* ------------------------------------------------------------------------- weight packing ---- */
+
+/* OIHW f32 -> [O][kh][kw][Ipad] in `dtype` (K contiguous): operand of ymi_conv2d_fwd.
+ * Ipad >= I, a multiple of 8 (bf16) / 4 (f32); padded channels are zero. */
+int ymi_pack_conv_weight_fwd(const float* w_oihw, int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t ipad, int32_t dtype, void* dst, void* stream);
+/* OIHW f32 -> operand of ymi_conv2d_bwd_data: for stride 1 one block [I][kh][kw][O] with taps
+ * flipped; for stride 2 the four output-parity classes back to back (sizes from
+ * ymi_conv_dgrad_pack_elems). */
+int ymi_pack_conv_weight_dgrad(const float* w_oihw, int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t stride, int32_t dtype, void* dst, void* stream);
+/* same, with the K axis (dy channels) zero-padded from o_real to o_pad rows. */
+int ymi_pack_conv_weight_dgrad_ex(const float* w_oihw, int64_t o_real, int64_t o_pad, int64_t i, int64_t kh, int64_t kw, int64_t stride, int32_t dtype, void* dst, void* stream);
+int64_t ymi_conv_dgrad_pack_elems(int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t stride);
+/* [rows][cols] f32 -> `dtype`, optionally transposed ([cols][rows]): nn.Linear / in_proj weights. */
+int ymi_pack_matrix(const float* src, int64_t rows, int64_t cols, int32_t transpose, int32_t dtype, void* dst, void* stream);
+
+/* ------------------------------------------------------------ convolution (implicit GEMM) ---- */
+
+/* y = act(scale[c] * conv(x, w) + bias[c]) + residual        (MFMA implicit GEMM, NHWC)
+ *   w: packed by ymi_pack_conv_weight_fwd with ipad == x->c;  pad = k/2 ("autopad", conv.py:28-34).
+ *   scale, bias, residual may be NULL.  If stat_partials != NULL the kernel also writes per-M-block
+ *   partial sums [blocks][2][cout] (sum, sum of squares of the ROUNDED outputs) for train-mode BN;
+ *   *host_stat_blocks receives `blocks`.  ymi_conv2d_stat_blocks() gives an upper bound for sizing.
+ * Replaces F.conv2d at nn/modules/conv.py:79,91 (Conv), nn/modules/head.py:45-59 (Detect stacks),
+ * nn/modules/cbam.py:24-26 is NOT routed here (tiny, fused in ymi_cbam_*).
+ * With kh=kw=1 and n*h*w = rows it is the token GEMM of nn/modules/swin_block.py:31-35,51,53. */
+int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                   const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
+                   float* stat_partials, int64_t* host_stat_blocks, void* stream);
+int64_t ymi_conv2d_stat_blocks(int64_t m_rows, int64_t cout);
+
+/* Train-mode BatchNorm2d statistics from the partials above (nn/modules/conv.py:66,79 with
+ * eps/momentum of utils/torch_utils.py:468-470): writes scale = gamma*invstd, shift = beta - mean*scale,
+ * save_mean, save_invstd, and updates running_mean / running_var (unbiased) in place. */
+int ymi_bn_finalize(const float* stat_partials, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, void* stream);
+/* out = act(raw*scale[c] + shift[c]) + residual : BN-affine + SiLU (+ Bottleneck add, block.py:488). */
+int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, const float* shift, int32_t act, const ymi_tensor* residual,
+                        const ymi_tensor* out, void* stream);
+
+/* Conv + train-mode BN + SiLU in one call: conv (raw, statistics) -> finalize -> affine+SiLU.
+ * `raw` (saved for backward) and `out` have y's shape; workspace >= ymi_conv2d_stat_blocks*2*cout*4 B
+ * + 2*cout*4 B.  Replaces Conv.forward, nn/modules/conv.py:69-79. */
+int ymi_conv2d_bn_silu_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                           const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                           float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
+                           float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Backward of act(BN_train(raw)) w.r.t. raw, two passes:
+ *  reduce: partial sums of dz and dz*xhat per channel, dz = dout * act'(raw*scale+shift)
+ *  apply : draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also dgamma, dbeta. */
+int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
+                   const float* save_invstd, const float* beta, int32_t act, const ymi_tensor* draw, float* dgamma, float* dbeta,
+                   void* workspace, size_t workspace_bytes, void* stream);
+/* dx = conv_transpose(dy, w): operand packed by ymi_pack_conv_weight_dgrad.  Adjoint of conv.py:79. */
+int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
+                        const ymi_tensor* dx, void* stream);
+/* dw (OIHW f32 [cout_real][cin_real][kh][kw], overwritten) = sum over pixels dy (x) x ; optional
+ * dbias[cout_real] = column sums of dy.  x / dy may carry zero-padded channels (x->c >= cin_real,
+ * dy->c >= cout_real).  Split-K MFMA GEMM + ordered slab reduce (deterministic); workspace from
+ * ymi_conv2d_bwd_weight_workspace. */
+int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
+                          int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
+size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, int64_t cin, int64_t kh, int64_t kw);
+
+/* -------------------------------------------------------------------- SPPF pooling cascade ---- */
+
+/* y1 = maxpool_k(y0), y2 = maxpool_k(y1), y3 = maxpool_k(y2), stride 1, pad k/2 (-inf):
+ * nn/modules/block.py:220,225.  One LDS-staged kernel; y1..y3 are usually channel slices of the
+ * concat buffer that SPPF.cv2 reads. */
+int ymi_sppf_pool3_fwd(const ymi_tensor* y0, int64_t k, const ymi_tensor* y1, const ymi_tensor* y2, const ymi_tensor* y3, void* stream);
+/* Adjoint of the cascade, stage by stage as a deterministic gather: dy2 += route(dy3|y2);
+ * dy1 += route(dy2|y1); dy0 += route(dy1|y0), each window's gradient going to its first arg-max in
+ * row-major order (PyTorch's max_pool2d tie rule).  dy1, dy2 are modified in place; dy0 must already
+ * hold the direct gradient of y0. */
+int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, const ymi_tensor* y2, int64_t k, const ymi_tensor* dy1,
+                       const ymi_tensor* dy2, const ymi_tensor* dy3, const ymi_tensor* dy0_accum, void* stream);
+
+/* -------------------------------------------------------------------------------- CBAM ---- */
+
+/* out = x * ca * sa with ca = sigmoid(MLP(avg) + MLP(max)) (nn/modules/cbam.py:29-38),
+ * sa = sigmoid(conv7x7([mean_c(x*ca), max_c(x*ca)])) (cbam.py:48-53), composed as cbam.py:62-71.
+ * w1: [hidden][C] f32, w2: [C][hidden] f32, wsa: [2][k][k] f32.  Saved for backward: ca [N][C] f32,
+ * smap [N][H][W][2] f32 (mean,max of x*ca), sa [N][H][W] f32, and the arg-max indices. */
+int ymi_cbam_fwd(const ymi_tensor* x, const float* w1, const float* w2, int64_t hidden, const float* wsa, int64_t ksa,
+                 const ymi_tensor* out, float* ca, float* pooled /*[N][2][C]*/, int32_t* pool_argmax /*[N][C]*/, float* smap,
+                 int32_t* smap_argmax /*[N][H][W]*/, float* sa, void* stream);
+int ymi_cbam_bwd(const ymi_tensor* x, const ymi_tensor* dout, const float* w1, const float* w2, int64_t hidden, const float* wsa,
+                 int64_t ksa, const float* ca, const float* pooled, const int32_t* pool_argmax, const float* smap,
+                 const int32_t* smap_argmax, const float* sa, const ymi_tensor* dx, float* dw1, float* dw2, float* dwsa,
+                 void* workspace, size_t workspace_bytes, void* stream);
+size_t ymi_cbam_bwd_workspace(int64_t n, int64_t h, int64_t w, int64_t c, int64_t hidden);
+
+/* ------------------------------------------------------------------------------ SwinBlock ---- */
+
+/* Integer index maps of nn/modules/swin_block.py:8-20 (bit-exact requirement): for window-ordered
+ * token t the flat padded-grid pixel index, tokens = n*hp*wp. */
+int ymi_window_partition_index(int64_t n, int64_t hp, int64_t wp, int64_t ws, int32_t* index, void* stream);
+/* tokens[t,:] = x[pixel(t),:] (zero where the pixel is padding) / inverse with crop. */
+int ymi_window_partition(const ymi_tensor* x, int64_t ws, const ymi_tensor* tokens /*n=1,h=1,w=T*/, void* stream);
+int ymi_window_reverse(const ymi_tensor* tokens, int64_t ws, const ymi_tensor* x, void* stream);
+/* t = LayerNorm(gather(x)) : pad + 'b c h w -> b h w c' + window_partition + norm1 fused
+ * (swin_block.py:41-50).  With ws == 0 no gather: plain row-wise LayerNorm (norm2, :53).
+ * Saves mean / rstd per token for backward. */
+int ymi_layernorm_fwd(const ymi_tensor* x, int64_t ws, const float* gamma, const float* beta, float eps, const ymi_tensor* out,
+                      float* mean, float* rstd, void* stream);
+/* dx = LayerNorm adjoint (written through the window map when ws != 0; pad tokens are dropped =
+ * the crop of :58); accumulate != 0 adds into dx instead (LayerNorm input that also feeds a skip). */
+int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tensor* dout, const float* gamma, const float* mean,
+                      const float* rstd, const ymi_tensor* dx, int32_t accumulate, float* dgamma, float* dbeta, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* Window attention core of nn.MultiheadAttention as used at swin_block.py:29,51:
+ * qkv [T][3C] (q pre-scaled is NOT assumed: the kernel scales by 1/sqrt(hd)); per (window, head)
+ * P = softmax(q k^T / sqrt(hd)) over all `wlen` keys, o = P v; out [T][C].  lse [T][heads] saved. */
+int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int64_t heads, const ymi_tensor* out, float* lse, void* stream);
+int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor* out, const ymi_tensor* dout, const float* lse, int64_t wlen,
+                             int64_t heads, const ymi_tensor* dqkv, void* stream);
+/* Generic token GEMM backward helpers (nn.Linear adjoint): column sums for bias gradients. */
+int ymi_colsum(const ymi_tensor* x, float* out /*[c]*/, void* workspace, size_t workspace_bytes, void* stream);
+/* dx = dy * gelu'(pre) (exact erf GELU, swin_block.py:33). */
+int ymi_gelu_bwd(const ymi_tensor* pre, const ymi_tensor* dy, const ymi_tensor* dx, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YMI_H */

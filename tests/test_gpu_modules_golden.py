@@ -1,0 +1,252 @@
+"""GPU parity: the HIP operator modules (through the C ABI) against the reference's own outputs
+(tests/golden/*.npz, produced by the real reference) and against the CPU oracle on seeded inputs.
+
+float32 runs are the parity gate (tolerance 1e-3, BASELINE.json north_star); bfloat16 runs check the
+fast path against the same references with a bf16-sized tolerance written next to each assert.
+"""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, golden_state, load_golden
+
+pytestmark = pytest.mark.gpu
+
+F32_TOL = dict(rtol=1e-3, atol=1e-3)  # north_star: within 1e-3 of the fp32 CPU reference
+BF16_TOL = dict(rtol=6e-2, atol=6e-2)  # bf16 has 8 significant bits; several chained ops
+
+
+def t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def P():
+    import improving_yolov8_cbam_swinblock_amd.nn.modules as M
+
+    return M
+
+
+def set_bn(m):
+    for b in m.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.eps, b.momentum = 1e-3, 0.03
+
+
+def run(m, x, dtype):
+    if dtype == torch.bfloat16:
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return m(x)
+    return m(x)
+
+
+def close(a, b, tol, what=""):
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert torch.isfinite(a).all(), f"{what}: non-finite output"
+    assert err <= tol["atol"] * scale + tol["rtol"] * 0, f"{what}: max abs err {err:.3e} (scale {scale:.3g}) > {tol['atol'] * scale:.3e}"
+
+
+def grads_of(y, inputs, gy):
+    return torch.autograd.grad(y, inputs, gy.to(y.dtype) if gy.dtype != y.dtype else gy, allow_unused=True)
+
+
+CASES = {
+    "conv_3x3_s1": lambda M: M.Conv(8, 16, 3, 1),
+    "conv_3x3_s2": lambda M: M.Conv(8, 16, 3, 2),
+    "conv_3x3_s2_c3": lambda M: M.Conv(3, 16, 3, 2),
+    "conv_1x1": lambda M: M.Conv(24, 16, 1, 1),
+    "bottleneck_add": lambda M: M.Bottleneck(16, 16, True, 1, k=((3, 3), (3, 3)), e=1.0),
+    "c2f_n2_shortcut": lambda M: M.C2f(16, 32, 2, True),
+    "c2f_n1_noshortcut": lambda M: M.C2f(24, 16, 1, False),
+    "sppf_k5": lambda M: M.SPPF(16, 16, 5),
+    "sppf_k7": lambda M: M.SPPF(16, 24, 7),
+}
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", list(CASES))
+def test_conv_family_vs_reference(name, dtype):
+    d = load_golden(name)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    m = CASES[name](P())
+    set_bn(m)
+    m.load_state_dict(golden_state(d), strict=True)
+    m = m.to(dev()).train()
+    x = t(d["x"]).to(dev()).requires_grad_(True)
+    y = run(m, x, dtype)
+    close(y, t(d["y_train"]), tol, f"{name} train fwd")
+    params = [p for p in m.parameters() if p.requires_grad]
+    names = ["x"] + [n for n, p in m.named_parameters() if p.requires_grad]
+    gs = grads_of(y, [x] + params, t(d["gy"]).to(dev()))
+    gtol = dict(atol=tol["atol"] * 2, rtol=0)
+    for n, g in zip(names, gs):
+        assert g is not None, f"{name}: no gradient for {n}"
+        close(g, t(d["g." + n]), gtol, f"{name} grad {n}")
+    sd = m.state_dict()
+    for k, v in golden_state(d, "after.").items():
+        close(sd[k].float(), v.float(), tol, f"{name} running stat {k}")
+    m.eval()
+    with torch.no_grad():
+        close(run(m, x.detach(), dtype), t(d["y_eval"]), tol, f"{name} eval fwd")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_conv_fused_eval(dtype):
+    from improving_yolov8_cbam_swinblock_amd.utils.torch_utils import fuse_conv_and_bn
+
+    d = load_golden("conv_fused_eval")
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    m = P().Conv(8, 16, 3, 1)
+    set_bn(m)
+    m.load_state_dict(golden_state(d), strict=True)
+    m = m.to(dev()).eval()
+    with torch.no_grad():
+        m.conv = fuse_conv_and_bn(m.conv, m.bn)
+        delattr(m, "bn")
+        close(m.conv.weight, t(d["fused_weight"]), F32_TOL, "fused weight")
+        y = run(m, t(d["x"]).to(dev()), dtype)
+    close(y, t(d["y"]), tol, "fused eval conv")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name,ctor_c", [("cbam_lazy_c32", None), ("cbam_c64", 64), ("cbam_lazy_c512", None)])
+def test_cbam_vs_reference(name, ctor_c, dtype):
+    d = load_golden(name)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    M = P()
+    m = M.CBAM(ctor_c) if ctor_c else M.CBAM()
+    if m.ca.shared_MLP is None:
+        m.ca.create_mlp(d["x"].shape[1])
+    m.load_state_dict(golden_state(d), strict=True)
+    m = m.to(dev())
+    x = t(d["x"]).to(dev()).requires_grad_(True)
+    y = run(m, x, dtype)
+    close(y, t(d["y"]), tol, f"{name} fwd")
+    names = ["x"] + [n for n, _ in m.named_parameters()]
+    gs = grads_of(y, [x] + list(m.parameters()), t(d["gy"]).to(dev()))
+    for n, g in zip(names, gs):
+        assert g is not None, n
+        close(g, t(d["g." + n]), dict(atol=tol["atol"] * 2, rtol=0), f"{name} grad {n}")
+
+
+def test_cbam_lazy_creates_mlp_on_device():
+    d = load_golden("cbam_lazy_c32")
+    m = P().CBAM().to(dev())
+    x = t(d["x"]).to(dev())
+    y = m(x)
+    assert m.ca.shared_MLP[0].weight.is_cuda and m.ca.shared_MLP[0].weight.shape == (2, 32, 1, 1)  # 32 // 16 = 2 (lazy rule)
+    assert y.shape == x.shape
+
+
+@pytest.mark.parametrize("hw", ["42x42", "84x84", "14x21"])
+def test_window_index_bit_exact(hw):
+    from improving_yolov8_cbam_swinblock_amd import ops
+
+    d = load_golden(f"window_index_{hw}_ws7")
+    B, H, W, ws = (int(v) for v in d["shape"])
+    idx = ops.window_partition_index(B, H, W, ws, dev()).cpu().numpy()
+    assert np.array_equal(idx.reshape(d["partition"].shape), d["partition"])
+    # partition / reverse as data movement: exact round trip and exact agreement with the index map
+    M = P()
+    x = torch.arange(B * H * W * 8, dtype=torch.float32, device=dev()).view(B, H, W, 8)
+    win = M.window_partition(x, ws)
+    ref = x.view(B * H * W, 8)[torch.from_numpy(d["partition"].astype(np.int64)).to(dev()).view(-1)].view(win.shape)
+    assert torch.equal(win, ref)
+    assert torch.equal(M.window_reverse(win, ws, H, W).contiguous(), x)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", ["swin_d32_7x7", "swin_d32_10x10", "swin_d64_14x21", "swin_d64_h4_20x20"])
+def test_swin_block_vs_reference(name, dtype):
+    d = load_golden(name)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    dim = d["x"].shape[1]
+    m = P().SwinBlock(dim, int(d["heads"]))
+    m.load_state_dict(golden_state(d), strict=True)
+    m = m.to(dev())
+    x = t(d["x"]).to(dev()).requires_grad_(True)
+    y = run(m, x, dtype)
+    close(y, t(d["y"]), tol, f"{name} fwd")
+    names = ["x"] + [n for n, _ in m.named_parameters()]
+    gs = grads_of(y, [x] + list(m.parameters()), t(d["gy"]).to(dev()))
+    for n, g in zip(names, gs):
+        assert g is not None, n
+        close(g, t(d["g." + n]), dict(atol=tol["atol"] * 3, rtol=0), f"{name} grad {n}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_detect_vs_reference(dtype):
+    d = load_golden("detect_nc3")
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    det = P().Detect(3, [16, 32, 64])
+    det.stride = torch.tensor([8.0, 16.0, 32.0])
+    set_bn(det)
+    det.load_state_dict(golden_state(d), strict=True)
+    det = det.to(dev())
+    det.stride = det.stride.to(dev())
+    xs = [t(d[f"x{i}"]).to(dev()) for i in range(3)]
+    det.train()
+    for i, y in enumerate(run(det, [v.clone() for v in xs], dtype)):
+        close(y, t(d[f"y_train{i}"]), tol, f"detect train level {i}")
+    det.eval()
+    with torch.no_grad():
+        ye, _ = run(det, [v.clone() for v in xs], dtype)
+    # decoded boxes are in pixels (up to ~300): compare relative to magnitude
+    close(ye, t(d["y_eval"]), dict(atol=tol["atol"] * (1 if dtype == torch.float32 else 2), rtol=0), "detect eval decode")
+
+
+def _tiny():
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+
+    cfg = json.loads((GOLDEN / "e2e_tiny_seed7_yaml.json").read_text())
+    d = load_golden("e2e_tiny_seed7")
+    model = DetectionModel(cfg, ch=3, nc=1)
+    missing = model.load_state_dict(golden_state(d), strict=True)
+    return model.to(dev()), d
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_e2e_tiny_model_vs_reference(dtype):
+    model, d = _tiny()
+    tol = F32_TOL if dtype == torch.float32 else dict(atol=0.15, rtol=0)  # 27 layers of bf16 + train-mode BN on 2 images
+    img = t(d["img"]).to(dev())
+    batch = {"img": img, "batch_idx": t(d["batch_idx"]).to(dev()), "cls": t(d["cls"]).to(dev()), "bboxes": t(d["bboxes"]).to(dev())}
+    model.train()
+    preds = run(model, img, dtype)
+    for i, p in enumerate(preds):
+        close(p, t(d[f"pred{i}"]), tol, f"e2e pred level {i}")
+    loss, items = model.criterion(preds, batch) if getattr(model, "criterion", None) else model.init_criterion()(preds, batch)
+    ltol = 2e-3 if dtype == torch.float32 else 0.1
+    assert torch.allclose(loss.float().cpu(), t(d["loss"]), rtol=ltol, atol=ltol), (loss, d["loss"])
+    loss.sum().backward()
+    ref = json.loads((GOLDEN / "e2e_tiny_seed7_gradnorms.json").read_text())
+    got = {n: float(p.grad.float().norm()) for n, p in model.named_parameters() if p.grad is not None}
+    assert set(got) == set(ref), set(got) ^ set(ref)
+    if dtype == torch.float32:
+        bad = {n: (got[n], v) for n, v in ref.items() if abs(got[n] - v) > 2e-2 * max(abs(v), 1e-2) + 1e-4}
+        assert not bad, bad
+    model.eval()
+    with torch.no_grad():
+        ye, _ = run(model, img, dtype)
+    close(ye, t(d["y_eval"]), dict(atol=tol["atol"], rtol=0), "e2e eval decode")
+
+
+def test_loss_matches_reference_on_fixed_predictions():
+    model, _ = _tiny()
+    d = load_golden("loss_crowded")
+    preds = [t(d[f"pred{i}"]).to(dev()).requires_grad_(True) for i in range(3)]
+    batch = {"batch_idx": t(d["batch_idx"]).to(dev()), "cls": t(d["cls"]).to(dev()), "bboxes": t(d["bboxes"]).to(dev())}
+    loss, items = model.init_criterion()(preds, batch)
+    assert torch.allclose(loss.cpu(), t(d["loss"]), rtol=1e-4, atol=1e-4), (loss, d["loss"])
+    loss.sum().backward()
+    for i, p in enumerate(preds):
+        assert torch.allclose(p.grad.cpu(), t(d[f"g.pred{i}"]), rtol=1e-3, atol=1e-5)
