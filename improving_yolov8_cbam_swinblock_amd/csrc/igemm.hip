@@ -330,11 +330,20 @@ static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) 
     return YMI_OK;
 }
 
+bool ymi_prof_enabled();
+int ymi_prof_start(hipStream_t stream, int family, double flop);
+void ymi_prof_stop(hipStream_t stream, int idx);
+
 int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
     TileChoice t = choose_tile(a.M, a.Cout);
     if (host_blocks) *host_blocks = (a.M + t.bm - 1) / t.bm;
-    if (dtype == YMI_BF16) return stats ? launch_igemm_t<bf16_t, true>(a, t, stream) : launch_igemm_t<bf16_t, false>(a, t, stream);
-    return stats ? launch_igemm_t<float, true>(a, t, stream) : launch_igemm_t<float, false>(a, t, stream);
+    int prof = -1;
+    if (ymi_prof_enabled()) prof = ymi_prof_start(stream, 0, 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot);
+    int rc;
+    if (dtype == YMI_BF16) rc = stats ? launch_igemm_t<bf16_t, true>(a, t, stream) : launch_igemm_t<bf16_t, false>(a, t, stream);
+    else rc = stats ? launch_igemm_t<float, true>(a, t, stream) : launch_igemm_t<float, false>(a, t, stream);
+    ymi_prof_stop(stream, prof);
+    return rc;
 }
 
 static void pack_taps(const int* dh, const int* dw, int n, uint64_t* pdh, uint64_t* pdw) {

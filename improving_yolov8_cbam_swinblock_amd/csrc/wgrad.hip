@@ -11,6 +11,9 @@
 #include "common.h"
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream);
+bool ymi_prof_enabled();
+int ymi_prof_start(hipStream_t stream, int family, double flop);
+void ymi_prof_stop(hipStream_t stream, int idx);
 
 struct WgradArgs {
     const void* x;
@@ -257,6 +260,8 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     a.CoutP = (int)dy->c; a.Cin = (int)x->c; a.NG = (int)ng; a.pix_per_split = p.pix_per_split;
     dim3 grid((unsigned)((ng + WG_BN - 1) / WG_BN), (unsigned)((dy->c + WG_BM - 1) / WG_BM), (unsigned)p.splits);
     hipStream_t s = (hipStream_t)stream;
+    int prof = -1;
+    if (ymi_prof_enabled()) prof = ymi_prof_start(s, 1, 2.0 * (double)mpix * (double)dy->c * (double)ng);
     if (x->dtype == YMI_BF16) {
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 2);
         hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), lds, s, a);
@@ -264,6 +269,7 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
         hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, s, a);
     }
+    ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");
     const int64_t total = cout_real * kh * kw * cin_real;
     int64_t gb = (total + 255) / 256;

@@ -140,14 +140,18 @@ def _wgrad(x, dy, cout, cin, k, stride, want_bias):
     return dw, db
 
 
-def _dgrad(dy, weight4, cin_out, k, stride, in_shape, dtype):
-    """dx [N, cin_out, H, W] (NHWC) from dy and the OIHW weight."""
-    n, _, h, w = in_shape
+def _dgrad(dy, weight4, k, stride, in_shape, dtype):
+    """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight; zero-padded input channels get zero."""
+    n, cp, h, w = in_shape
+    cin = weight4.shape[1]
     ty = as_ymi(dy)
     wd = pack_conv_dgrad(weight4, ty.c, stride, dtype)
-    if len(in_shape) == 4:
-        dx = empty_nhwc(n, cin_out, h, w, dtype, dy.device)
-    check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), cin_out, k, k, stride, _byref(as_ymi(dx)), stream_ptr()), "conv2d_bwd_data")
+    dx = empty_nhwc(n, cp, h, w, dtype, dy.device)
+    dxv = dx
+    if cp != cin:
+        dx.zero_()
+        dxv = dx[:, :cin]
+    check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), cin, k, k, stride, _byref(as_ymi(dxv)), stream_ptr()), "conv2d_bwd_data")
     return dx
 
 
@@ -201,7 +205,7 @@ class _ConvBnAct(torch.autograd.Function):
         )
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _dgrad(draw, weight, x.shape[1], k, stride, x.shape, dtype)
+            dx = _dgrad(draw, weight, k, stride, x.shape, dtype)
         dw, _ = _wgrad(x, draw, o, cin, k, stride, False)
         dres = dout if (has_res and ctx.needs_input_grad[10]) else None
         return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, dres
@@ -268,7 +272,7 @@ class _ConvAffineAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if x.dim() == 4:
-                dx = _dgrad(dy, w4, x.shape[1], k, stride, x.shape, dtype)
+                dx = _dgrad(dy, w4, k, stride, x.shape, dtype)
             else:
                 ty = as_ymi(dy)
                 wd = pack_conv_dgrad(w4, ty.c, 1, dtype)

@@ -49,6 +49,13 @@ typedef struct ymi_tensor {
 int ymi_version(void);
 const char* ymi_last_error(void);
 
+/* Optional live timing of the MFMA GEMM kernels (HIP events on the launch stream) for bench.py's roofline
+ * line.  begin(): pre-create events for `capacity` launches and start recording; end(): synchronise the
+ * device and return per-family totals (family 0: implicit-GEMM conv forward / data-gradient / token GEMMs,
+ * family 1: weight-gradient GEMM): elapsed ms, algorithmic FLOP (2*M*N*K of the launch), launch count. */
+int ymi_profile_begin(int64_t capacity);
+int ymi_profile_end(double* ms_by_family, double* flop_by_family, int64_t* launches_by_family);
+
 /* ---------------------------------------------------------------- layout / data movement ---- */
 
 /* NCHW f32 image -> NHWC (dst.dtype), channels c..dst.c-1 zero-filled.  Replaces the implicit

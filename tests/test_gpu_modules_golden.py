@@ -55,6 +55,16 @@ def close(a, b, tol, what=""):
     assert err <= tol["atol"] * scale + tol["rtol"] * 0, f"{what}: max abs err {err:.3e} (scale {scale:.3g}) > {tol['atol'] * scale:.3e}"
 
 
+def close_l2(a, b, rel, what=""):
+    """relative L2 error: for bf16 runs of ops with arg-max routing (max-pool, CBAM) a single near-tie decided
+    differently moves one element by O(1), which max-abs would flag although the tensor is right."""
+    a = a.detach().float().cpu()
+    b = b.detach().float().cpu()
+    assert a.shape == b.shape and torch.isfinite(a).all(), what
+    err = float((a - b).norm() / b.norm().clamp(min=1e-6))
+    assert err <= rel, f"{what}: relative L2 error {err:.3e} > {rel:.1e}"
+
+
 def grads_of(y, inputs, gy):
     return torch.autograd.grad(y, inputs, gy.to(y.dtype) if gy.dtype != y.dtype else gy, allow_unused=True)
 
@@ -135,7 +145,10 @@ def test_cbam_vs_reference(name, ctor_c, dtype):
     gs = grads_of(y, [x] + list(m.parameters()), t(d["gy"]).to(dev()))
     for n, g in zip(names, gs):
         assert g is not None, n
-        close(g, t(d["g." + n]), dict(atol=tol["atol"] * 2, rtol=0), f"{name} grad {n}")
+        if dtype == torch.float32:
+            close(g, t(d["g." + n]), dict(atol=tol["atol"] * 2, rtol=0), f"{name} grad {n}")
+        else:
+            close_l2(g, t(d["g." + n]), 0.08, f"{name} grad {n}")
 
 
 def test_cbam_lazy_creates_mlp_on_device():
@@ -223,7 +236,10 @@ def test_e2e_tiny_model_vs_reference(dtype):
     model.train()
     preds = run(model, img, dtype)
     for i, p in enumerate(preds):
-        close(p, t(d[f"pred{i}"]), tol, f"e2e pred level {i}")
+        if dtype == torch.float32:
+            close(p, t(d[f"pred{i}"]), tol, f"e2e pred level {i}")
+        else:  # 27 bf16 layers with train-mode BN over 2 images (8 values per channel at P5): compare in norm
+            close_l2(p, t(d[f"pred{i}"]), 0.12, f"e2e pred level {i}")
     loss, items = model.criterion(preds, batch) if getattr(model, "criterion", None) else model.init_criterion()(preds, batch)
     ltol = 2e-3 if dtype == torch.float32 else 0.1
     assert torch.allclose(loss.float().cpu(), t(d["loss"]), rtol=ltol, atol=ltol), (loss, d["loss"])
@@ -237,7 +253,10 @@ def test_e2e_tiny_model_vs_reference(dtype):
     model.eval()
     with torch.no_grad():
         ye, _ = run(model, img, dtype)
-    close(ye, t(d["y_eval"]), dict(atol=tol["atol"], rtol=0), "e2e eval decode")
+    if dtype == torch.float32:
+        close(ye, t(d["y_eval"]), dict(atol=tol["atol"], rtol=0), "e2e eval decode")
+    else:
+        close_l2(ye, t(d["y_eval"]), 0.05, "e2e eval decode")
 
 
 def test_loss_matches_reference_on_fixed_predictions():
