@@ -27,12 +27,13 @@ GFLOP_PER_IMG_FWD_BWD = 103.87  # SURVEY.md section 8(d), measured on the refere
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(batch=4, iters=3):
+def cpu_baseline(batch=2, iters=4):
     """reference's CPU path as restated by the oracle: fwd + v8 loss + bwd, fp32, all host cores."""
     from oracle.loss import v8DetectionLoss
     from oracle.tasks import DetectionModel
 
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
+    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     model = DetectionModel("yolov8s.yaml", ch=3, nc=1)
@@ -54,9 +55,14 @@ def cpu_baseline(batch=4, iters=3):
 
     step()  # warm-up
     t0 = time.perf_counter()
+    done = 0
     for _ in range(iters):
         step()
+        done += 1
+        if time.perf_counter() - t0 > 30.0:  # bounded sample
+            break
     dt = time.perf_counter() - t0
+    iters = done
     return {
         "value": round(batch * iters / dt, 3),
         "unit": "images/sec",

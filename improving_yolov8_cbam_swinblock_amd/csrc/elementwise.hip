@@ -305,11 +305,45 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int blocks, d
     }
 }
 
+// First stage for long partial lists (layer 0 at bs 32 has 25,600 rows): R row-groups in parallel, each
+// summed in double and stored as float, IN PLACE over the first R rows' slots of a separate region.
+__global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __restrict__ part, int blocks, int C, int R, float* __restrict__ out) {
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int g = blockIdx.y;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (int b = g + R * slice; b < blocks; b += 4 * R) {
+            s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
+            s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
+        }
+    red[0][slice][cl] = s1;
+    red[1][slice][cl] = s2;
+    __syncthreads();
+    if (slice == 0 && c < C) {
+        out[((int64_t)g * 2 + 0) * C + c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
+        out[((int64_t)g * 2 + 1) * C + c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+    }
+}
+
+constexpr int BN_STAGE_ROWS = 64;
+
+// `part` may be overwritten beyond row `blocks` (callers size it with ymi_conv2d_stat_blocks + BN_STAGE_ROWS rows).
 extern "C" int ymi_bn_finalize(const float* part, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
                                float* rmean, float* rvar, float momentum, float eps, float* scale, float* shift, float* smean,
                                float* sinv, void* stream) {
     YMI_CHECK_ARG(part && scale && shift && blocks > 0 && count > 0 && c > 0, "bn_finalize: args");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(256), 0, (hipStream_t)stream, part, (int)blocks,
+    const float* src = part;
+    int rows = (int)blocks;
+    if (blocks > 4 * BN_STAGE_ROWS) {
+        float* stage = const_cast<float*>(part) + blocks * 2 * c;  // scratch rows after the partials
+        hipLaunchKernelGGL(stat_rows_reduce_kernel, dim3((unsigned)((c + 63) / 64), BN_STAGE_ROWS), dim3(256), 0, (hipStream_t)stream, part,
+                           (int)blocks, (int)c, BN_STAGE_ROWS, stage);
+        src = stage;
+        rows = BN_STAGE_ROWS;
+    }
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, rows,
                        (double)count, (int)c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv);
     YMI_CHECK_LAUNCH("bn_finalize");
     return YMI_OK;
@@ -347,6 +381,50 @@ __global__ void scale_shift_act_kernel(TV x, const float* __restrict__ scale, co
     }
 }
 
+// Fast path: the number of 4-channel groups divides the block size, so a thread keeps ONE channel group for
+// all its pixels and holds scale/shift in registers; 8-byte (bf16) / 16-byte (f32) accesses, coalesced along C.
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                    TV res, TV o, int groups, int64_t P) {
+    const int g = threadIdx.x % groups;
+    const int rows_per_block = 256 / groups;
+    float sc[4], sh[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        sc[r] = scale ? scale[g * 4 + r] : 1.0f;
+        sh[r] = shift ? shift[g * 4 + r] : 0.0f;
+    }
+    const T* xp = reinterpret_cast<const T*>(x.p);
+    const T* rp = reinterpret_cast<const T*>(res.p);
+    T* op = reinterpret_cast<T*>(o.p);
+    for (int64_t p = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / groups; p < P; p += (int64_t)gridDim.x * rows_per_block) {
+        float v[4];
+        Pack<T, 4>::load(xp + p * x.ld + g * 4, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT>(v[r] * sc[r] + sh[r]);
+        if (rp) {
+            float rr[4];
+            Pack<T, 4>::load(rp + p * res.ld + g * 4, rr);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+        }
+        Pack<T, 4>::store(op + p * o.ld + g * 4, v);
+    }
+}
+
+template <typename T>
+static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const float* shift, int act, TV r, const ymi_tensor* out, hipStream_t s) {
+    const int groups = (int)raw->c / 4;
+    const int64_t P = ymi_pixels(raw);
+    const int rows = 256 / groups;
+    int64_t gb = (P + rows - 1) / rows;
+    if (gb > 256 * 16) gb = 256 * 16;
+    dim3 g((unsigned)gb), b(256);
+    if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
+    else if (act == YMI_ACT_GELU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_GELU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
+    else hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_NONE>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
+}
+
 extern "C" int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, const float* shift, int32_t act, const ymi_tensor* residual,
                                    const ymi_tensor* out, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(raw) && ymi_tensor_ok(out) && ymi_same_shape(raw, out) && raw->dtype == out->dtype, "scale_shift_act: shapes");
@@ -356,6 +434,12 @@ extern "C" int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, co
     TV r = residual ? tv(residual) : TV{nullptr, 0, 0, 0, 0, 0};
     dim3 g = ew_grid(total), b(256);
     hipStream_t s = (hipStream_t)stream;
+    if (vec && raw->c / 4 <= 256 && 256 % (raw->c / 4) == 0) {
+        if (raw->dtype == YMI_BF16) launch_ssa_fixed<bf16_t>(raw, scale, shift, act, r, out, s);
+        else launch_ssa_fixed<float>(raw, scale, shift, act, r, out, s);
+        YMI_CHECK_LAUNCH("scale_shift_act");
+        return YMI_OK;
+    }
     if (raw->dtype == YMI_BF16) {
         if (vec) hipLaunchKernelGGL((scale_shift_act_kernel<bf16_t, true>), g, b, 0, s, tv(raw), scale, shift, act, r, tv(out));
         else hipLaunchKernelGGL((scale_shift_act_kernel<bf16_t, false>), g, b, 0, s, tv(raw), scale, shift, act, r, tv(out));

@@ -358,7 +358,7 @@ static void pack_taps(const int* dh, const int* dw, int n, uint64_t* pdh, uint64
 
 extern "C" int64_t ymi_conv2d_stat_blocks(int64_t m_rows, int64_t cout) {
     (void)cout;
-    return (m_rows + 63) / 64;  // smallest BM any tile choice uses
+    return (m_rows + 63) / 64 + 64;  // smallest BM any tile choice uses, + the 64 staging rows ymi_bn_finalize may append
 }
 
 extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,

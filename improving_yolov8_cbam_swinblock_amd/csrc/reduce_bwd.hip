@@ -84,14 +84,14 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
     }
 }
 
-// stage 2: out0[c] = sum_b part[b][0][c] (* scale), out1[c] = sum_b part[b][1][c] (* scale)
-__global__ void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ double red[2][4][64];
+// stage 2: out0[c] = sum_b part[b][0][c], out1[c] = sum_b part[b][1][c]   (64 channels x 16 row slices per block)
+__global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1) {
+    __shared__ double red[2][16][64];
     const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     double s0 = 0.0, s1 = 0.0;
     if (c < C)
-        for (int b = slice; b < blocks; b += 4) {
+        for (int b = slice; b < blocks; b += 16) {
             s0 += (double)part[((int64_t)b * 2 + 0) * C + c];
             s1 += (double)part[((int64_t)b * 2 + 1) * C + c];
         }
@@ -99,8 +99,14 @@ __global__ void chan_reduce_final_kernel(const float* __restrict__ part, int blo
     red[1][slice][cl] = s1;
     __syncthreads();
     if (slice == 0 && c < C) {
-        if (out0) out0[c] = (float)(red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl]);
-        if (out1) out1[c] = (float)(red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl]);
+        double a = 0.0, b2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            a += red[0][q][cl];
+            b2 += red[1][q][cl];
+        }
+        if (out0) out0[c] = (float)a;
+        if (out1) out1[c] = (float)b2;
     }
 }
 
@@ -113,7 +119,7 @@ static int pow2_ge(int v) {
 // returns number of stage-1 blocks; partials must hold blocks*2*C floats
 static int reduce_blocks(int64_t P) {
     int64_t b = (P + 255) / 256;  // >= 256 pixels per block
-    if (b > 1024) b = 1024;
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -138,7 +144,7 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
 }
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream) {
-    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, part, blocks, C, out0, out1);
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, part, blocks, C, out0, out1);
     YMI_CHECK_LAUNCH("chan_reduce_final");
     return YMI_OK;
 }
@@ -171,30 +177,60 @@ int ymi_ln_param_grads(const ymi_tensor* dy, const ymi_tensor* x, const float* m
 }
 
 // draw = gamma*inv*(dz - mean(dz) - xhat*mean(dz*xhat))
-template <typename T>
-__global__ void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t P, int C, const float* __restrict__ gamma,
-                                        const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ inv,
-                                        const float* __restrict__ sum_dz, const float* __restrict__ sum_dzx, float inv_count, int act) {
+// FIXED: the number of 4-channel groups divides 256, so a thread keeps one channel group and its
+// per-channel coefficients in registers for all of its pixels.
+template <typename T, bool FIXED>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t P, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, const float* __restrict__ mean,
+                                                               const float* __restrict__ inv, const float* __restrict__ sum_dz,
+                                                               const float* __restrict__ sum_dzx, float inv_count, int act) {
     const int groups = C / 4;
-    const int64_t total = P * groups;
     const T* dp = reinterpret_cast<const T*>(dout.p);
     const T* rp = reinterpret_cast<const T*>(raw.p);
     T* op = reinterpret_cast<T*>(const_cast<void*>(draw.p));
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const int64_t p = i / groups;
-        float d[4], x[4], o[4];
-        Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
-        Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+    if constexpr (FIXED) {
+        const int g = threadIdx.x % groups, rows = 256 / groups;
+        float ga[4], be[4], p0[4], p1[4], k1[4], k2[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = g * 4 + r;
-            const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
-            const float xh = (x[r] - mean[c]) * inv[c];
-            const float dz = d[r] * act_grad_rt(xh * ga + be, act);
-            o[r] = ga * inv[c] * (dz - sum_dz[c] * inv_count - xh * sum_dzx[c] * inv_count);
+            ga[r] = gamma ? gamma[c] : 1.0f;
+            be[r] = beta ? beta[c] : 0.0f;
+            p0[r] = inv[c];
+            p1[r] = -mean[c] * inv[c];
+            k1[r] = sum_dz[c] * inv_count;
+            k2[r] = sum_dzx[c] * inv_count;
         }
-        Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
+        for (int64_t p = (int64_t)blockIdx.x * rows + threadIdx.x / groups; p < P; p += (int64_t)gridDim.x * rows) {
+            float d[4], x[4], o[4];
+            Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
+            Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float xh = x[r] * p0[r] + p1[r];
+                const float dz = d[r] * act_grad_rt(xh * ga[r] + be[r], act);
+                o[r] = ga[r] * p0[r] * (dz - k1[r] - xh * k2[r]);
+            }
+            Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
+        }
+    } else {
+        const int64_t total = P * groups;
+        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+            const int g = (int)(i % groups);
+            const int64_t p = i / groups;
+            float d[4], x[4], o[4];
+            Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
+            Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = g * 4 + r;
+                const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
+                const float xh = (x[r] - mean[c]) * inv[c];
+                const float dz = d[r] * act_grad_rt(xh * ga + be, act);
+                o[r] = ga * inv[c] * (dz - sum_dz[c] * inv_count - xh * sum_dzx[c] * inv_count);
+            }
+            Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
+        }
     }
 }
 
@@ -219,14 +255,22 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     if (rc) return rc;
     rc = ymi_chan_reduce_final((const float*)workspace, blocks, C, dbeta, dgamma, s);  // dbeta = sum dz, dgamma = sum dz*xhat
     if (rc) return rc;
-    const int64_t total = P * (C / 4);
-    int64_t gb = (total + 255) / 256;
+    const int groups = C / 4;
+    const bool fixed = groups <= 256 && 256 % groups == 0;
+    const int64_t total = P * groups;
+    int64_t gb = fixed ? (P + 256 / groups - 1) / (256 / groups) : (total + 255) / 256;
     if (gb > 4096) gb = 4096;
     RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
-    if (dout->dtype == YMI_BF16)
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<bf16_t>, dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, 1.0f / (float)P, act);
-    else
-        hipLaunchKernelGGL(bn_act_bwd_apply_kernel<float>, dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, 1.0f / (float)P, act);
+    const float ic = 1.0f / (float)P;
+#define YMI_BWD_APPLY(T, F) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, F>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, ic, act)
+    if (dout->dtype == YMI_BF16) {
+        if (fixed) YMI_BWD_APPLY(bf16_t, true);
+        else YMI_BWD_APPLY(bf16_t, false);
+    } else {
+        if (fixed) YMI_BWD_APPLY(float, true);
+        else YMI_BWD_APPLY(float, false);
+    }
+#undef YMI_BWD_APPLY
     YMI_CHECK_LAUNCH("bn_act_bwd(apply)");
     return YMI_OK;
 }

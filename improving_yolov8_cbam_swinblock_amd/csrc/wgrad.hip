@@ -188,7 +188,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
 }
 
-// dw[co][ci][kh][kw] = sum_s slab[s][co][tap*Cin + ci]
+// Slab reduction in two parallel stages (both deterministic):
+//  stage 1: grid (elements/256, R): group g sums slabs g, g+R, ... element-wise (coalesced) into stage[g][:]
+//  stage 2: dw[co][ci][kh][kw] = sum_g stage[g][co][tap*Cin + ci]   (scatter into OIHW)
+__global__ __launch_bounds__(256) void wgrad_stage_kernel(const float* __restrict__ slab, int splits, int64_t elems, int R, float* __restrict__ stage) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= elems) return;
+    const int g = blockIdx.y;
+    float s = 0.f;
+    for (int k = g; k < splits; k += R) s += slab[(int64_t)k * elems + e];
+    stage[(int64_t)g * elems + e] = s;
+}
+
 __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real, int cin_real,
                                     int ntaps, float* __restrict__ dw) {
     const int64_t total = (int64_t)cout_real * ntaps * cin_real;
@@ -203,6 +214,8 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
         dw[((int64_t)co * cin_real + ci) * ntaps + tap] = s;
     }
 }
+
+constexpr int WG_STAGE_R = 16;
 
 struct WgradPlan {
     int splits, pix_per_split;
@@ -220,7 +233,7 @@ static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng) {
     WgradPlan p;
     p.splits = (int)s;
     p.pix_per_split = (int)pps;
-    p.slab_bytes = (size_t)s * coutp * ng * sizeof(float);
+    p.slab_bytes = (size_t)(s + WG_STAGE_R) * coutp * ng * sizeof(float);  // + staging rows of the two-stage reduce
     return p;
 }
 
@@ -274,7 +287,16 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     const int64_t total = cout_real * kh * kw * cin_real;
     int64_t gb = (total + 255) / 256;
     if (gb > 2048) gb = 2048;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, (const float*)a.slab, p.splits, a.CoutP, a.NG, a.Cin,
+    const float* red_src = a.slab;
+    int red_splits = p.splits;
+    if (p.splits > 2 * WG_STAGE_R) {
+        const int64_t elems = (int64_t)a.CoutP * a.NG;
+        float* stage = a.slab + (int64_t)p.splits * elems;
+        hipLaunchKernelGGL(wgrad_stage_kernel, dim3((unsigned)((elems + 255) / 256), WG_STAGE_R), dim3(256), 0, s, (const float*)a.slab, p.splits, elems, WG_STAGE_R, stage);
+        red_src = stage;
+        red_splits = WG_STAGE_R;
+    }
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, red_src, red_splits, a.CoutP, a.NG, a.Cin,
                        (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
     YMI_CHECK_LAUNCH("wgrad_reduce");
     if (dbias) {

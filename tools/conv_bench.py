@@ -1,0 +1,114 @@
+"""Per-layer timing of the three MFMA GEMM kernels on the conv shapes of YOLOv8s-CBAM-Swin at bs=32, 640x640
+(and the Swin token GEMMs).  Development tool: prints one line per shape with TFLOP/s for forward (raw+stats),
+data gradient and weight gradient.   python tools/conv_bench.py [--dtype bf16|f32] [--iters 20]"""
+import argparse
+import ctypes
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from improving_yolov8_cbam_swinblock_amd import _lib, ops  # noqa: E402
+
+# (name, cin, cout, k, stride, H_in) at bs=32 ; count = occurrences in the model
+SHAPES = [
+    ("L0 3->32 s2", 8, 32, 3, 2, 640, 1),
+    ("L1 32->64 s2", 32, 64, 3, 2, 320, 1),
+    ("c2f2.cv1 64->64 1x1", 64, 64, 1, 1, 160, 1),
+    ("c2f2.m 32->32 3x3", 32, 32, 3, 1, 160, 2),
+    ("c2f2.cv2 96->64 1x1", 96, 64, 1, 1, 160, 1),
+    ("L3 64->128 s2", 64, 128, 3, 2, 160, 1),
+    ("c2f4.cv1 128->128 1x1", 128, 128, 1, 1, 80, 1),
+    ("c2f4.m 64->64 3x3", 64, 64, 3, 1, 80, 4),
+    ("c2f4.cv2 256->128 1x1", 256, 128, 1, 1, 80, 1),
+    ("L5 128->256 s2", 128, 256, 3, 2, 80, 1),
+    ("c2f6.cv1 256->256 1x1", 256, 256, 1, 1, 40, 1),
+    ("c2f6.m 128->128 3x3", 128, 128, 3, 1, 40, 4),
+    ("c2f6.cv2 512->256 1x1", 512, 256, 1, 1, 40, 1),
+    ("L8 256->512 s2", 256, 512, 3, 2, 40, 1),
+    ("c2f9.cv1 512->512 1x1", 512, 512, 1, 1, 20, 1),
+    ("c2f9.m 256->256 3x3", 256, 256, 3, 1, 20, 2),
+    ("c2f9.cv2 768->512 1x1", 768, 512, 1, 1, 20, 1),
+    ("sppf.cv1 512->256 1x1", 512, 256, 1, 1, 20, 2),
+    ("sppf.cv2 1024->512 1x1", 1024, 512, 1, 1, 20, 2),
+    ("c2f15.cv1 768->256 1x1", 768, 256, 1, 1, 40, 1),
+    ("c2f19.cv1 384->128 1x1", 384, 128, 1, 1, 80, 1),
+    ("c2f19.cv2 192->128 1x1", 192, 128, 1, 1, 80, 1),
+    ("L20 128->128 s2", 128, 128, 3, 2, 80, 1),
+    ("L23 256->256 s2", 256, 256, 3, 2, 40, 1),
+    ("det.cv2[0] 128->64 3x3", 128, 64, 3, 1, 80, 1),
+    ("det.cv3[0] 128->128 3x3", 128, 128, 3, 1, 80, 2),
+    ("det.cv2[1] 256->64 3x3", 256, 64, 3, 1, 40, 1),
+    ("det.cv3[1] 256->128 3x3", 256, 128, 3, 1, 40, 1),
+    ("det.cv2[2] 512->64 3x3", 512, 64, 3, 1, 20, 1),
+    ("det.cv3[2] 512->128 3x3", 512, 128, 3, 1, 20, 1),
+    ("swin.qkv 256->768 tok", 256, 768, 1, 1, -56448, 2),
+    ("swin.fc1 256->1024 tok", 256, 1024, 1, 1, -56448, 2),
+    ("swin.fc2 1024->256 tok", 1024, 256, 1, 1, -56448, 2),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    args = ap.parse_args()
+    dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    dev = torch.device("cuda:0")
+    L = _lib.lib()
+    tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
+    print(f"{'shape':28s} {'M':>9s} {'GF':>7s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | {'wgrad us':>8s} {'TF':>6s}")
+    for name, cin, cout, k, s, h, count in SHAPES:
+        w = torch.randn(cout, cin, k, k, device=dev) * 0.05
+        if h < 0:
+            x = torch.randn(-h, cin, device=dev).to(dt)
+            M = -h
+            y = torch.empty(M, cout, dtype=dt, device=dev)
+        else:
+            x = ops.empty_nhwc(args.batch, cin, h, h, dt, dev)
+            x.copy_(torch.randn(args.batch, cin, h, h, device=dev))
+            ho = (h + 2 * (k // 2) - k) // s + 1
+            M = args.batch * ho * ho
+            y = ops.empty_nhwc(args.batch, cout, ho, ho, dt, dev)
+        wp = ops.pack_conv_fwd(w, cin, dt)
+        wd = ops.pack_conv_dgrad(w, cout, s, dt)
+        part = torch.empty(int(L.ymi_conv2d_stat_blocks(M, cout)) * 2 * cout, dtype=torch.float32, device=dev)
+        dy = torch.randn_like(y.float()).to(dt) if h < 0 else ops.empty_nhwc(*y.shape, dt, dev).copy_(torch.randn(y.shape, device=dev))
+        dx = torch.empty_like(x) if h < 0 else ops.empty_nhwc(*x.shape, dt, dev)
+        dw = torch.empty(cout, cin, k, k, device=dev)
+        ws = torch.empty(int(L.ymi_conv2d_bwd_weight_workspace(M, cout, cin, k, k)), dtype=torch.uint8, device=dev)
+        nb = ctypes.c_int64(0)
+        tx, ty, tdy, tdx = _lib.as_ymi(x), _lib.as_ymi(y), _lib.as_ymi(dy), _lib.as_ymi(dx)
+        sp = _lib.stream_ptr()
+
+        def fwd():
+            _lib.check(L.ymi_conv2d_fwd(ctypes.byref(tx), _lib.ptr(wp), cout, k, k, s, None, None, 0, None, ctypes.byref(ty), _lib.ptr(part), ctypes.byref(nb), sp))
+
+        def dgrad():
+            _lib.check(L.ymi_conv2d_bwd_data(ctypes.byref(tdy), _lib.ptr(wd), cin, k, k, s, ctypes.byref(tdx), sp))
+
+        def wgrad():
+            _lib.check(L.ymi_conv2d_bwd_weight(ctypes.byref(tx), ctypes.byref(tdy), cout, cin, k, k, s, _lib.ptr(dw), None, _lib.ptr(ws), ws.numel(), sp))
+
+        gf = 2.0 * M * cout * cin * k * k / 1e9
+        line = f"{name:28s} {M:9d} {gf:7.1f} |"
+        for nm, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+            for _ in range(3):
+                fn()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(args.iters):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            tot[nm] += us * count
+            line += f" {us:8.1f} {gf / us * 1e-3 * 1e3 / 1e3 * 1e3:6.0f} |" if False else f" {us:8.1f} {gf / (us * 1e-6) / 1e3:6.0f} |"
+        print(line, flush=True)
+    print("model totals (us, weighted by occurrence):", {k: round(v) for k, v in tot.items()})
+
+
+if __name__ == "__main__":
+    main()
