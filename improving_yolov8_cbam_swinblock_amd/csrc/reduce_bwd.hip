@@ -35,10 +35,7 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
             mu[r] = (FN == 1) ? mean[c] : 0.0f;
             iv[r] = (FN == 1) ? inv[c] : 1.0f;
         }
-        for (int64_t p = p0 + ty; p < p1; p += rows) {
-            float va[4], vb[4];
-            Pack<T, 4>::load(ap + p * a.ld + tx * 4, va);
-            if (FN != 0) Pack<T, 4>::load(bp + p * b.ld + tx * 4, vb);
+        auto accum = [&](const float (&va)[4], const float (&vb)[4], int64_t p) {
             if (FN == 0) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) s0[r] += va[r];
@@ -58,6 +55,24 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
                     s1[r] += va[r] * (vb[r] - m) * rs;
                 }
             }
+        };
+        int64_t p = p0 + ty;
+        // 4 pixels per trip: 8 independent 8/16-byte loads in flight per lane before the first use
+        for (; p + 3 * (int64_t)rows < p1; p += 4 * (int64_t)rows) {
+            float va[4][4], vb[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Pack<T, 4>::load(ap + (p + u * (int64_t)rows) * a.ld + tx * 4, va[u]);
+                if (FN != 0) Pack<T, 4>::load(bp + (p + u * (int64_t)rows) * b.ld + tx * 4, vb[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) accum(va[u], vb[u], p + u * (int64_t)rows);
+        }
+        for (; p < p1; p += rows) {
+            float va[4], vb[4];
+            Pack<T, 4>::load(ap + p * a.ld + tx * 4, va);
+            if (FN != 0) Pack<T, 4>::load(bp + p * b.ld + tx * 4, vb);
+            accum(va, vb, p);
         }
     }
     float* my = red + ((size_t)ty * TG + tx) * 8;
@@ -118,8 +133,8 @@ static int pow2_ge(int v) {
 
 // returns number of stage-1 blocks; partials must hold blocks*2*C floats
 static int reduce_blocks(int64_t P) {
-    int64_t b = (P + 255) / 256;  // >= 256 pixels per block
-    if (b > 512) b = 512;
+    int64_t b = (P + 63) / 64;  // >= 64 pixels per block
+    if (b > 2048) b = 2048;
     if (b < 1) b = 1;
     return (int)b;
 }

@@ -243,7 +243,7 @@ extern "C" size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, 
     // upper bound over both dtypes' channel padding (8), plus room for the bias-gradient partials
     const int64_t coutp = pad_to(cout, 8), cinp = pad_to(cin, 8);
     WgradPlan p = wgrad_plan(m_rows, coutp, kh * kw * cinp);
-    return p.slab_bytes + (size_t)(1024 * 2 + 1) * coutp * sizeof(float) + 256;
+    return p.slab_bytes + (size_t)(2048 * 2 + 1) * coutp * sizeof(float) + 256;
 }
 
 extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
@@ -260,7 +260,7 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     const int64_t mpix = ymi_pixels(dy);
     const int64_t ng = kh * kw * x->c;
     WgradPlan p = wgrad_plan(mpix, dy->c, ng);
-    size_t need = p.slab_bytes + (dbias ? (size_t)(1024 * 2 + 1) * dy->c * sizeof(float) : 0);
+    size_t need = p.slab_bytes + (dbias ? (size_t)(2048 * 2 + 1) * dy->c * sizeof(float) : 0);
     if (workspace_bytes < need) {
         ymi_set_error("conv2d_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
         return YMI_EWORKSPACE;
@@ -302,8 +302,8 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     if (dbias) {
         // bias gradient: column sums of dy (first cout_real channels are the real ones)
         float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.slab_bytes);
-        float* sums = part + (size_t)1024 * 2 * dy->c;
-        int rc = ymi_colsum(dy, sums, part, (size_t)1024 * 2 * dy->c * sizeof(float), stream);
+        float* sums = part + (size_t)2048 * 2 * dy->c;
+        int rc = ymi_colsum(dy, sums, part, (size_t)2048 * 2 * dy->c * sizeof(float), stream);
         if (rc) return rc;
         // copy the real channels out
         hipError_t e = hipMemcpyAsync(dbias, sums, cout_real * sizeof(float), hipMemcpyDeviceToDevice, s);

@@ -76,6 +76,16 @@ class Detect(nn.Module):
         y = self._inference(x)
         return y if self.export else (y, x)
 
+    def forward_split(self, x):
+        """train-mode maps WITHOUT the per-level concat (the loss splits them again, reference loss.py:205-207):
+        -> (box list [B, 64, H, W], cls list [B, nc, H, W]).  Used by DetectionModel.loss."""
+        box, cls = [], []
+        for i in range(self.nl):
+            xi = ops.to_internal(x[i])
+            box.append(self.cv2[i](xi))
+            cls.append(self.cv3[i](xi))
+        return box, cls
+
     def _inference(self, x):
         """reference head.py:103-142, non-export branch (decode of [B, no, 8400]: small torch ops)."""
         shape = x[0].shape

@@ -15,7 +15,7 @@ import torch.nn as nn
 import yaml
 
 from .. import ops
-from ..utils.loss import DEFAULT_HYP, v8DetectionLoss
+from ..utils.loss import DEFAULT_HYP, SplitPreds, v8DetectionLoss
 from ..utils.ops import make_divisible
 from ..utils.torch_utils import fuse_conv_and_bn, initialize_weights, intersect_dicts
 from .modules import C2f, CBAM, SPPF, Bottleneck, Concat, Conv, Detect, SwinBlock, Upsample
@@ -131,14 +131,18 @@ class BaseModel(nn.Module):
     def predict(self, x, profile=False, visualize=False, augment=False, embed=None):
         return self._predict_once(x)
 
-    def _predict_once(self, x, profile=False, visualize=False, embed=None):
-        """the 27-step module loop of reference tasks.py:152-179."""
+    def _predict_once(self, x, profile=False, visualize=False, embed=None, split_head=False):
+        """the 27-step module loop of reference tasks.py:152-179.  split_head: return Detect's maps before
+        its channel concat (training loss fast path)."""
         y = []
-        for m in self.model:
-            if m.f != -1:
-                x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
-            x = m(x)
-            y.append(x if m.i in self.save else None)
+        with ops.deferred_bn_counters():
+            for m in self.model:
+                if m.f != -1:
+                    x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                if split_head and isinstance(m, Detect):
+                    return SplitPreds(*m.forward_split(x))
+                x = m(x)
+                y.append(x if m.i in self.save else None)
         return x
 
     def fuse(self, verbose=False):
@@ -176,7 +180,8 @@ class BaseModel(nn.Module):
     def loss(self, batch, preds=None):
         if getattr(self, "criterion", None) is None:
             self.criterion = self.init_criterion()
-        preds = self.forward(batch["img"]) if preds is None else preds
+        if preds is None:
+            preds = self._predict_once(batch["img"], split_head=self.training)
         return self.criterion(preds, batch)
 
     def init_criterion(self):

@@ -196,11 +196,13 @@ class _ConvBnAct(torch.autograd.Function):
         dev = x.device
         dout = grad_nhwc(dout, dtype)
         draw = empty_nhwc(*raw.shape, dtype, dev)
-        dgb = torch.empty((2, o), dtype=torch.float32, device=dev)
-        ws = workspace(1024 * 2 * o * 4 + 256, dev, "bnbwd")
+        # two separate tensors: AccumulateGrad adopts them as .grad without a clone (views would be copied)
+        dgamma = torch.empty(o, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(o, dtype=torch.float32, device=dev)
+        ws = workspace(2048 * 2 * o * 4 + 256, dev, "bnbwd")
         check(
             L().ymi_bn_act_bwd(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(beta), act,
-                               _byref(as_ymi(draw)), ptr(dgb[0]), ptr(dgb[1]), ptr(ws), ws.numel(), stream_ptr()),
+                               _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
             "bn_act_bwd",
         )
         dx = None
@@ -208,7 +210,7 @@ class _ConvBnAct(torch.autograd.Function):
             dx = _dgrad(draw, weight, k, stride, x.shape, dtype)
         dw, _ = _wgrad(x, draw, o, cin, k, stride, False)
         dres = dout if (has_res and ctx.needs_input_grad[10]) else None
-        return dx, dw, dgb[0], dgb[1], None, None, None, None, None, None, dres
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres
 
 
 def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None):
@@ -217,8 +219,32 @@ def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None):
         raise RuntimeError("BatchNorm with cumulative moving average (momentum=None) is not supported")
     out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual)
     if bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _deferred_counters is not None:
+            _deferred_counters.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     return out
+
+
+_deferred_counters = None
+
+
+class deferred_bn_counters:
+    """inside this context the `num_batches_tracked += 1` of every Conv is collected and applied as ONE
+    multi-tensor add on exit (59 tiny launches -> 1 per forward)."""
+
+    def __enter__(self):
+        global _deferred_counters
+        self.prev = _deferred_counters
+        _deferred_counters = []
+        return self
+
+    def __exit__(self, *exc):
+        global _deferred_counters
+        pending, _deferred_counters = _deferred_counters, self.prev
+        if pending:
+            torch._foreach_add_(pending, 1)
+        return False
 
 
 # ------------------------------------------------------------------- conv / linear with affine epilogue

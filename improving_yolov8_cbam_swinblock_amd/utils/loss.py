@@ -18,6 +18,13 @@ from ..nn.modules.head import dist2bbox, make_anchors
 DEFAULT_HYP = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)  # reference cfg/default.yaml:98-100
 
 
+class SplitPreds:
+    """train-mode Detect output before the channel concat: box[i] [B, 64, H, W], cls[i] [B, nc, H, W]."""
+
+    def __init__(self, box, cls):
+        self.box, self.cls = box, cls
+
+
 def bbox_ciou(b1, b2, eps=1e-7):
     """CIoU for xyxy boxes broadcast over leading dims (reference metrics.py:74-134, xywh=False, CIoU=True)."""
     x1, y1, x2, y2 = b1.unbind(-1)
@@ -116,13 +123,21 @@ class v8DetectionLoss:
         return out
 
     def __call__(self, preds, batch):
-        feats = preds[1] if isinstance(preds, tuple) else preds
-        B = feats[0].shape[0]
         dev = self.device
-        cat = torch.cat([f.float().reshape(B, self.no, -1) for f in feats], 2)
-        pred_distri, pred_scores = cat.split((self.reg_max * 4, self.nc), 1)
-        pred_scores = pred_scores.permute(0, 2, 1).contiguous()
-        pred_distri = pred_distri.permute(0, 2, 1).contiguous()
+        if isinstance(preds, SplitPreds):
+            # fast path from Detect.forward_split: per-level box / class maps in NHWC memory -> [B, A, .] are
+            # (almost) free views; gradients come back in the layout the conv backward kernels consume
+            feats = preds.box
+            B = feats[0].shape[0]
+            pred_distri = torch.cat([b.permute(0, 2, 3, 1).reshape(B, -1, self.reg_max * 4) for b in preds.box], 1).float()
+            pred_scores = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1, self.nc) for c in preds.cls], 1).float()
+        else:
+            feats = preds[1] if isinstance(preds, tuple) else preds
+            B = feats[0].shape[0]
+            cat = torch.cat([f.float().reshape(B, self.no, -1) for f in feats], 2)
+            pred_distri, pred_scores = cat.split((self.reg_max * 4, self.nc), 1)
+            pred_scores = pred_scores.permute(0, 2, 1).contiguous()
+            pred_distri = pred_distri.permute(0, 2, 1).contiguous()
         stride = self.stride.to(dev)
         imgsz = torch.tensor(feats[0].shape[2:], device=dev, dtype=torch.float) * stride[0]
         anchor_points, stride_tensor = make_anchors(feats, stride, 0.5)
@@ -132,7 +147,7 @@ class v8DetectionLoss:
         mask_gt = gt_bboxes.sum(2, keepdim=True).gt(0.0).float()
 
         b, a, c = pred_distri.shape
-        dist = pred_distri.view(b, a, 4, c // 4).softmax(3).matmul(self.proj)
+        dist = (pred_distri.view(b, a, 4, c // 4).softmax(3) * self.proj).sum(-1)  # expectation (reference: .matmul(proj))
         pred_bboxes = dist2bbox(dist, anchor_points, xywh=False)
 
         target_bboxes, target_scores, fg = self.assigner(

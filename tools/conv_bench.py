@@ -54,6 +54,8 @@ def main():
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--only", default="", help="substring filter on the shape name")
+    ap.add_argument("--ops", default="fwd,dgrad,wgrad")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -61,6 +63,8 @@ def main():
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print(f"{'shape':28s} {'M':>9s} {'GF':>7s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | {'wgrad us':>8s} {'TF':>6s}")
     for name, cin, cout, k, s, h, count in SHAPES:
+        if args.only and args.only not in name:
+            continue
         w = torch.randn(cout, cin, k, k, device=dev) * 0.05
         if h < 0:
             x = torch.randn(-h, cin, device=dev).to(dt)
@@ -95,6 +99,8 @@ def main():
         gf = 2.0 * M * cout * cin * k * k / 1e9
         line = f"{name:28s} {M:9d} {gf:7.1f} |"
         for nm, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
+            if nm not in args.ops.split(","):
+                continue
             for _ in range(3):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
