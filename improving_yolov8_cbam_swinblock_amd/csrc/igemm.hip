@@ -14,7 +14,14 @@
 //    (32 bf16 / 16 f32): both operand tiles are [rows][64 B] images in LDS.
 //  * tiles are filled with global_load_lds_dwordx4 (16 B per lane straight into LDS, no VGPR
 //    staging).  The LDS destination is lane-linear, so the bank-conflict swizzle
-//    chunk' = chunk ^ ((row>>2)&3) is applied to the per-lane SOURCE address and again on the read.
+//    chunk' = chunk ^ ((-(row>>2))&3) is applied to the per-lane SOURCE address and again on the read
+//    (rows r and r+4 share banks: 4 rows x 64 B = one 256-B bank row; this map gives every 16-lane group
+//    of ds_read_b128 sixteen distinct 16-byte slots).
+//  * NS-stage LDS ring: LDS-DMA for K step kt+NS-1 is issued while step kt is multiplied; steps are retired
+//    with a COUNTED s_waitcnt vmcnt(N) + one raw s_barrier per K step, so NS-2 steps of loads stay in flight
+//    across barriers (the kernel was latency-bound with a single prefetch stage: 3000 cycles per K step).
+//  * when Cin is a multiple of the K step (every layer but the first) the tap is wave-uniform and the
+//    im2col pixel address / bounds test is computed once per tap, not per K step.
 //  * MFMA operands are swapped (A = weights, B = activations): the 16x16 accumulator then holds 4
 //    consecutive CHANNELS of one pixel per lane, which is a contiguous 8/16-byte NHWC store.
 //  * bf16: v_mfma_f32_16x16x32_bf16; f32 parity mode: v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).
@@ -48,7 +55,7 @@ template <> struct Mma<bf16_t> {
     template <int TM, int TN>
     static __device__ __forceinline__ void step(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM]) {
         const int l15 = lane & 15, l4 = lane >> 4;
-        const int sw = ((l15 >> 2) & 3);
+        const int sw = (-(l15 >> 2)) & 3;  // g(q) = (-q)&3: conflict-free for the 4x16-lane groups of ds_read_b128
         const int coff = ((l4 ^ sw) << 4);
         bf16x8 wf[TN], xf[TM];
 #pragma unroll
@@ -66,7 +73,7 @@ template <> struct Mma<float> {
     template <int TM, int TN>
     static __device__ __forceinline__ void step(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM]) {
         const int l15 = lane & 15, l4 = lane >> 4;
-        const int sw = ((l15 >> 2) & 3);
+        const int sw = (-(l15 >> 2)) & 3;  // g(q) = (-q)&3: conflict-free for the 4x16-lane groups of ds_read_b128
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int coff = ((ks ^ sw) << 4) + (l4 << 2);
@@ -83,35 +90,48 @@ template <> struct Mma<float> {
     }
 };
 
-template <typename T, int BM, int BN, int WM, int WN, bool STATS>
+
+template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
+    // retire all but the N youngest vector-memory operations of this wave, then meet the workgroup: data
+    // written to LDS by LDS-DMA becomes readable by other waves only after BOTH (counted wait, then barrier).
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int NS, bool FAST, bool STATS>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256;
     constexpr int STAGE = (BM + BN) * 64;
     static_assert(WM * WN == 4, "4 waves");
+    static_assert(BM % 64 == 0, "every wave issues all A loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a CONTIGUOUS range of
+    // M blocks (neighbouring pixel tiles share 3x3 halo rows and hit the same L2).  Bijective for any grid size.
+    int mb;
+    {
+        const int nmb = gridDim.x, orig = blockIdx.x;
+        const int q = nmb >> 3, r = nmb & 7, xcd = orig & 7;
+        mb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    }
+    const int m0 = mb * BM, n0 = blockIdx.y * BN;
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
     const T* zero = reinterpret_cast<const T*>(a.zero);
 
     // ---- per-thread load descriptors -----------------------------------------------------------
-    const int c = (tid & 3) ^ ((tid >> 4) & 3);  // source chunk (0..3) of the K step this thread fetches
-    int tap = c / a.cpt;
-    int cic = c - tap * a.cpt;
-    const int adv_tap = 4 / a.cpt, adv_c = 4 - adv_tap * a.cpt;  // one K step = 4 chunks further along (tap, ci)
+    const int c = (tid & 3) ^ ((-(tid >> 4)) & 3);  // source chunk (0..3) of the K step this thread fetches (swizzle)
     int a_nH[NA], a_h[NA], a_w[NA];
     bool a_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
         const int r = (tid >> 2) + 64 * i;
         const int m = m0 + r;
-        a_ok[i] = (m < a.M) && (r < BM);
+        a_ok[i] = (m < a.M);
         const int mm = a_ok[i] ? m : 0;
         const int wo = mm % a.Wo;
         const int t = mm / a.Wo;
@@ -131,34 +151,78 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         b_ptr[j] = wg + (int64_t)(b_ok[j] ? n : 0) * a.ktot;
     }
 
+    // K iterator.  FAST (Cin % K-step == 0): the tap is wave-uniform, `cic` is this thread's chunk inside the
+    // tap, and the per-row pixel address / bounds test is refreshed once per tap.  Otherwise (first layer,
+    // Cin = 8): every chunk of a K step may belong to a different tap and is decoded per step.
+    int tap = FAST ? 0 : c / a.cpt;
+    int cic = FAST ? c : c - tap * a.cpt;
+    const int adv_tap = 4 / a.cpt, adv_c = 4 - adv_tap * a.cpt;
+    const T* a_base[NA];
+    bool a_in[NA];
+    auto setup_tap = [&](int tp) {
+        const int dh = (int)((a.tap_dh >> (4 * tp)) & 15) - 8;
+        const int dw = (int)((a.tap_dw >> (4 * tp)) & 15) - 8;
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int hi = a_h[i] + dh, wi = a_w[i] + dw;
+            a_in[i] = a_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            a_base[i] = xg + ((int64_t)(a_nH[i] + hi) * a.W + wi) * a.ldx;
+        }
+    };
+    if (FAST) {
+        setup_tap(0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) b_ptr[j] += c * CH;
+    }
+
     auto issue = [&](int s) {
         char* As = smem + s * STAGE;
         char* Bs = As + BM * 64;
-        const bool kvalid = tap < a.ntaps;
-        const int dh = (int)((a.tap_dh >> (4 * (tap & 15))) & 15) - 8;
-        const int dw = (int)((a.tap_dw >> (4 * (tap & 15))) & 15) - 8;
+        if constexpr (FAST) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            if ((wave * 16 + 64 * i) < BM) {  // wave-uniform
+            for (int i = 0; i < NA; ++i) {
+                const T* src = a_in[i] ? a_base[i] + cic * CH : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if ((wave * 16 + 64 * j) < BN) {  // wave-uniform
+                    const T* src = b_ok[j] ? b_ptr[j] : zero;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+                    b_ptr[j] += 4 * CH;
+                }
+            }
+            cic += 4;
+            if (cic >= a.cpt) {  // next tap (uniform: Cin is a multiple of the K step)
+                cic -= a.cpt;
+                ++tap;
+                if (tap < a.ntaps) setup_tap(tap);
+            }
+        } else {
+            const bool kvalid = tap < a.ntaps;
+            const int dh = (int)((a.tap_dh >> (4 * (tap & 15))) & 15) - 8;
+            const int dw = (int)((a.tap_dw >> (4 * (tap & 15))) & 15) - 8;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
                 const int hi = a_h[i] + dh, wi = a_w[i] + dw;
                 const bool ok = a_ok[i] && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 const T* src = ok ? xg + ((int64_t)(a_nH[i] + hi) * a.W + wi) * a.ldx + cic * CH : zero;
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
             }
-        }
 #pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if ((wave * 16 + 64 * j) < BN) {  // wave-uniform
-                const bool ok = b_ok[j] && kvalid;
-                const T* src = ok ? b_ptr[j] + (int64_t)(tap * a.cpt + cic) * CH : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+            for (int j = 0; j < NB; ++j) {
+                if ((wave * 16 + 64 * j) < BN) {  // wave-uniform
+                    const bool ok = b_ok[j] && kvalid;
+                    const T* src = ok ? b_ptr[j] + (int64_t)(tap * a.cpt + cic) * CH : zero;
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+                }
             }
-        }
-        cic += adv_c;
-        tap += adv_tap;
-        if (cic >= a.cpt) {
-            cic -= a.cpt;
-            ++tap;
+            cic += adv_c;
+            tap += adv_tap;
+            if (cic >= a.cpt) {
+                cic -= a.cpt;
+                ++tap;
+            }
         }
     };
 
@@ -168,17 +232,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // loads this wave issues per K step (vmcnt counts LDS-DMA operations per wave, in order)
+    constexpr int LPT_FULL = NA + NB;
+    constexpr int LPT_AONLY = NA;  // waves beyond the B tile's rows (BN < 64) issue no B loads
+    const bool b_wave = (BN >= 64) || (wave * 16 < BN);
     const int nkt = (a.KC + 3) >> 2;
-    issue(0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nkt) issue(s);
     for (int kt = 0; kt < nkt; ++kt) {
-        if (kt + 1 < nkt) issue((kt + 1) & 1);
-        const char* As = smem + (kt & 1) * STAGE;
+        // K step kt has landed when at most the loads of the NS-2 younger steps are outstanding
+        if (kt + NS - 2 < nkt) {
+            if (b_wave) wait_vmcnt_barrier<LPT_FULL * (NS - 2)>();
+            else wait_vmcnt_barrier<LPT_AONLY * (NS - 2)>();
+        } else {
+            wait_vmcnt_barrier<0>();  // pipeline tail: fewer steps in flight than the count assumes
+        }
+        // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
+        if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
+        const char* As = smem + (kt % NS) * STAGE;
         Mma<T>::template step<TM, TN>(As, As + BM * 64, wm * TM * 16, wn * TN * 16, lane, acc);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
     }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
 
     // ---- epilogue -----------------------------------------------------------------------------
     const int l15 = lane & 15, l4 = lane >> 4;
@@ -250,7 +325,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
 #pragma unroll
             for (int q = 0; q < WM; ++q) s += red[(q * 2 + which) * BN + chl];
             const int ch = n0 + chl;
-            if (ch < a.Cout) a.partials[((int64_t)blockIdx.x * 2 + which) * a.Cout + ch] = s;
+            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.Cout + ch] = s;
         }
     } else {
         const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
@@ -310,17 +385,23 @@ static TileChoice choose_tile(int64_t M, int64_t cout) {
     return t;
 }
 
+// LDS ring depth per tile: 128x128 -> 3 stages (48 KiB, 3 workgroups per CU), smaller tiles -> 4 stages
 template <typename T, bool STATS>
 static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) {
     dim3 grid((a.M + t.bm - 1) / t.bm, (a.Cout + t.bn - 1) / t.bn);
-    const size_t lds = 2 * (size_t)(t.bm + t.bn) * 64;
-#define YMI_LAUNCH(BM, BN, WM, WN)                                                                           \
-    hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, STATS>), grid, dim3(256), lds, stream, a)
-    if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2);
-    else if (t.bm == 128 && t.bn == 64) YMI_LAUNCH(128, 64, 2, 2);
-    else if (t.bm == 128 && t.bn == 32) YMI_LAUNCH(128, 32, 4, 1);
-    else if (t.bm == 64 && t.bn == 128) YMI_LAUNCH(64, 128, 2, 2);
-    else if (t.bm == 64 && t.bn == 64) YMI_LAUNCH(64, 64, 2, 2);
+    const bool fast = (a.cpt % 4) == 0;
+    const int ns = (t.bm == 128 && t.bn == 128) ? 3 : 4;
+    const size_t lds = (size_t)ns * (t.bm + t.bn) * 64;
+#define YMI_LAUNCH(BM, BN, WM, WN, NS)                                                                                     \
+    do {                                                                                                                   \
+        if (fast) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, true, STATS>), grid, dim3(256), lds, stream, a); \
+        else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, false, STATS>), grid, dim3(256), lds, stream, a);     \
+    } while (0)
+    if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2, 3);
+    else if (t.bm == 128 && t.bn == 64) YMI_LAUNCH(128, 64, 2, 2, 4);
+    else if (t.bm == 128 && t.bn == 32) YMI_LAUNCH(128, 32, 4, 1, 4);
+    else if (t.bm == 64 && t.bn == 128) YMI_LAUNCH(64, 128, 2, 2, 4);
+    else if (t.bm == 64 && t.bn == 64) YMI_LAUNCH(64, 64, 2, 2, 4);
     else {
         ymi_set_error("igemm: no tile %dx%d", t.bm, t.bn);
         return YMI_EINVAL;
