@@ -121,6 +121,12 @@ __device__ __forceinline__ float act_grad_rt(float x, int act) {
     return act == YMI_ACT_SILU ? silu_grad_f(x) : act == YMI_ACT_GELU ? gelu_grad_f(x) : 1.0f;
 }
 
+// retire all but the N youngest vector-memory operations of this wave, then meet the workgroup: bytes written
+// to LDS by LDS-DMA (global_load_lds) are readable by other waves only after BOTH (counted wait, then barrier).
+template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 // wave-level reductions (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

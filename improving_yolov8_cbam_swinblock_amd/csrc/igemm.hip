@@ -27,6 +27,8 @@
 //  * bf16: v_mfma_f32_16x16x32_bf16; f32 parity mode: v_mfma_f32_16x16x4_f32 (exact f32 FMA chain).
 //  * epilogue variants: (a) raw output + deterministic per-block BatchNorm partial sums
 //    (no atomics), (b) scale/bias/activation/residual.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct IgemmArgs {
@@ -90,12 +92,6 @@ template <> struct Mma<float> {
     }
 };
 
-
-template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
-    // retire all but the N youngest vector-memory operations of this wave, then meet the workgroup: data
-    // written to LDS by LDS-DMA becomes readable by other waves only after BOTH (counted wait, then barrier).
-    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
-}
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, bool FAST, bool STATS>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
@@ -385,28 +381,37 @@ static TileChoice choose_tile(int64_t M, int64_t cout) {
     return t;
 }
 
-// LDS ring depth per tile: 128x128 -> 3 stages (48 KiB, 3 workgroups per CU), smaller tiles -> 4 stages
+// LDS ring depth: tuning knob YMI_IGEMM_NS (2..4).  Measured on the model's shapes: deeper rings cost occupancy
+// (the kernel is bound by the L1/TA path, not by latency), see DESIGN.md.
 template <typename T, bool STATS>
 static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) {
     dim3 grid((a.M + t.bm - 1) / t.bm, (a.Cout + t.bn - 1) / t.bn);
     const bool fast = (a.cpt % 4) == 0;
-    const int ns = (t.bm == 128 && t.bn == 128) ? 3 : 4;
+    static const int ns_env = getenv("YMI_IGEMM_NS") ? atoi(getenv("YMI_IGEMM_NS")) : 0;
+    const int ns = ns_env >= 2 && ns_env <= 4 ? ns_env : 2;
     const size_t lds = (size_t)ns * (t.bm + t.bn) * 64;
-#define YMI_LAUNCH(BM, BN, WM, WN, NS)                                                                                     \
+#define YMI_LAUNCH2(BM, BN, WM, WN, NS)                                                                                    \
     do {                                                                                                                   \
         if (fast) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, true, STATS>), grid, dim3(256), lds, stream, a); \
         else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, false, STATS>), grid, dim3(256), lds, stream, a);     \
     } while (0)
-    if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2, 3);
-    else if (t.bm == 128 && t.bn == 64) YMI_LAUNCH(128, 64, 2, 2, 4);
-    else if (t.bm == 128 && t.bn == 32) YMI_LAUNCH(128, 32, 4, 1, 4);
-    else if (t.bm == 64 && t.bn == 128) YMI_LAUNCH(64, 128, 2, 2, 4);
-    else if (t.bm == 64 && t.bn == 64) YMI_LAUNCH(64, 64, 2, 2, 4);
+#define YMI_LAUNCH(BM, BN, WM, WN)                     \
+    do {                                               \
+        if (ns == 2) YMI_LAUNCH2(BM, BN, WM, WN, 2);   \
+        else if (ns == 3) YMI_LAUNCH2(BM, BN, WM, WN, 3); \
+        else YMI_LAUNCH2(BM, BN, WM, WN, 4);           \
+    } while (0)
+    if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2);
+    else if (t.bm == 128 && t.bn == 64) YMI_LAUNCH(128, 64, 2, 2);
+    else if (t.bm == 128 && t.bn == 32) YMI_LAUNCH(128, 32, 4, 1);
+    else if (t.bm == 64 && t.bn == 128) YMI_LAUNCH(64, 128, 2, 2);
+    else if (t.bm == 64 && t.bn == 64) YMI_LAUNCH(64, 64, 2, 2);
     else {
         ymi_set_error("igemm: no tile %dx%d", t.bm, t.bn);
         return YMI_EINVAL;
     }
 #undef YMI_LAUNCH
+#undef YMI_LAUNCH2
     YMI_CHECK_LAUNCH("igemm");
     return YMI_OK;
 }

@@ -99,24 +99,40 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
     }
 }
 
-// stage 2: out0[c] = sum_b part[b][0][c], out1[c] = sum_b part[b][1][c]   (64 channels x 16 row slices per block)
+// stage 2: out0[c] = sum_b part[b][0][c], out1[c] = sum_b part[b][1][c]
+// 32 channels x 32 row slices per block, 4 independent accumulator pairs per thread (loads in flight)
 __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1) {
-    __shared__ double red[2][16][64];
-    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s0 = 0.0, s1 = 0.0;
-    if (c < C)
-        for (int b = slice; b < blocks; b += 16) {
-            s0 += (double)part[((int64_t)b * 2 + 0) * C + c];
-            s1 += (double)part[((int64_t)b * 2 + 1) * C + c];
+    if (c < C) {
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
+        int b = slice;
+        for (; b + 96 < blocks; b += 128) {
+            a0 += part[((int64_t)b * 2 + 0) * C + c];
+            a1 += part[((int64_t)b * 2 + 1) * C + c];
+            b0 += part[((int64_t)(b + 32) * 2 + 0) * C + c];
+            b1 += part[((int64_t)(b + 32) * 2 + 1) * C + c];
+            c0 += part[((int64_t)(b + 64) * 2 + 0) * C + c];
+            c1 += part[((int64_t)(b + 64) * 2 + 1) * C + c];
+            d0 += part[((int64_t)(b + 96) * 2 + 0) * C + c];
+            d1 += part[((int64_t)(b + 96) * 2 + 1) * C + c];
         }
+        for (; b < blocks; b += 32) {
+            a0 += part[((int64_t)b * 2 + 0) * C + c];
+            a1 += part[((int64_t)b * 2 + 1) * C + c];
+        }
+        s0 = ((double)a0 + (double)b0) + ((double)c0 + (double)d0);
+        s1 = ((double)a1 + (double)b1) + ((double)c1 + (double)d1);
+    }
     red[0][slice][cl] = s0;
     red[1][slice][cl] = s1;
     __syncthreads();
     if (slice == 0 && c < C) {
         double a = 0.0, b2 = 0.0;
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
+        for (int q = 0; q < 32; ++q) {
             a += red[0][q][cl];
             b2 += red[1][q][cl];
         }
@@ -134,7 +150,7 @@ static int pow2_ge(int v) {
 // returns number of stage-1 blocks; partials must hold blocks*2*C floats
 static int reduce_blocks(int64_t P) {
     int64_t b = (P + 63) / 64;  // >= 64 pixels per block
-    if (b > 2048) b = 2048;
+    if (b > 1024) b = 1024;
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -159,7 +175,7 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
 }
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream) {
-    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 63) / 64), dim3(1024), 0, stream, part, blocks, C, out0, out1);
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, blocks, C, out0, out1);
     YMI_CHECK_LAUNCH("chan_reduce_final");
     return YMI_OK;
 }

@@ -8,6 +8,8 @@
 // mode, 16x16x4 MFMA).  The pixel axis is split across workgroups (grid.z); each split writes an f32
 // slab, a second kernel sums the slabs in a fixed order (deterministic, no atomics) and scatters into
 // the reference's OIHW layout.
+#include <stdlib.h>
+
 #include "common.h"
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream);
@@ -79,7 +81,7 @@ template <> struct WFrag<float> {
     }
 };
 
-template <typename T>
+template <typename T, int NS>
 __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
@@ -159,18 +161,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
 #pragma unroll
         for (int c = 0; c < TC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // NS-stage LDS ring, one raw barrier per K step, loads of NS-2 younger steps stay in flight (see igemm.hip)
     const int nk = (m_end - m_begin + WG_BK - 1) / WG_BK;
-    if (nk > 0) {
-        issue(0, m_begin);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + 1 < nk) issue((kt + 1) & 1, m_begin + (kt + 1) * WG_BK);
-            const char* Ys = smem + (kt & 1) * STAGE;
-            WFrag<T>::template step<TR, TC>(Ys, Ys + YBYTES, wr * 32, wc * 64, lane, acc);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-        }
+    constexpr int LPT = NY + NX;
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s)
+        if (s < nk) issue(s, m_begin + s * WG_BK);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + NS - 2 < nk) wait_vmcnt_barrier<LPT * (NS - 2)>();
+        else wait_vmcnt_barrier<0>();
+        if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, m_begin + (kt + NS - 1) * WG_BK);
+        const char* Ys = smem + (kt % NS) * STAGE;
+        WFrag<T>::template step<TR, TC>(Ys, Ys + YBYTES, wr * 32, wc * 64, lane, acc);
     }
 
     float* slab = a.slab + (int64_t)blockIdx.z * a.CoutP * a.NG;
@@ -276,11 +278,15 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     int prof = -1;
     if (ymi_prof_enabled()) prof = ymi_prof_start(s, 1, 2.0 * (double)mpix * (double)dy->c * (double)ng);
     if (x->dtype == YMI_BF16) {
-        const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 2);
-        hipLaunchKernelGGL(wgrad_kernel<bf16_t>, grid, dim3(256), lds, s, a);
+        static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
+        const size_t lds = (size_t)ns * (size_t)(WG_BK * (WG_BM + WG_BN) * 2);
+        if (ns == 4) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 4>), grid, dim3(256), lds, s, a);
+        else if (ns == 3) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2>), grid, dim3(256), lds, s, a);
     } else {
-        const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
-        hipLaunchKernelGGL(wgrad_kernel<float>, grid, dim3(256), lds, s, a);
+        const size_t lds = 3 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        hipLaunchKernelGGL((wgrad_kernel<float, 3>), grid, dim3(256), lds, s, a);
     }
     ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");

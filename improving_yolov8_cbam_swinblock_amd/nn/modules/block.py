@@ -50,9 +50,8 @@ class C2f(nn.Module):
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
     def forward(self, x):
-        t = self.cv1(x)
-        ys = [t]  # both chunks at once: they are adjacent in memory
-        last = t[:, self.c :]
+        t, last = ops.c2f_split(self.cv1(x), self.c)  # (both chunks, second chunk): channel slices, no copy
+        ys = [t]  # both chunks go into the concat at once: they are adjacent in memory
         for m in self.m:
             last = m(last)
             ys.append(last)

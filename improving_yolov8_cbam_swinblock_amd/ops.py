@@ -382,6 +382,39 @@ def concat(xs):
     return _Concat.apply(*xs)
 
 
+class _C2fSplit(torch.autograd.Function):
+    """C2f's `chunk(2, 1)` (block.py:302) without autograd's slice bookkeeping: returns (t, right half of t) as
+    views.  Backward receives the gradient of the whole tensor (from the concat) and of the right half (from the
+    first Bottleneck) in ONE call and adds the latter into the former's right half in place with one kernel,
+    instead of zero-fill + copy + strided add (three passes over the tensor)."""
+
+    @staticmethod
+    def forward(ctx, t, c):
+        ctx.c = c
+        ctx.shape = t.shape
+        return t.view_as(t), t[:, c:]
+
+    @staticmethod
+    def backward(ctx, g_full, g_right):
+        c = ctx.c
+        if g_full is None:
+            n, c2, h, w = ctx.shape
+            g_full = empty_nhwc(n, c2, h, w, g_right.dtype, g_right.device)
+            g_full.zero_()
+        if g_right is not None:
+            dt = g_full.dtype
+            if not _dense_ok(g_full, dt):
+                g_full = grad_nhwc(g_full, dt)
+            g_right = grad_nhwc(g_right, dt)
+            # g_full is the (privately owned) output of the consumer conv's data-gradient kernel
+            check(L().ymi_add_inplace(_byref(as_ymi(g_right)), _byref(as_ymi(g_full[:, c:])), stream_ptr()), "add_inplace")
+        return g_full, None
+
+
+def c2f_split(t, c):
+    return _C2fSplit.apply(t, int(c))
+
+
 class _Upsample2x(torch.autograd.Function):
     """nn.Upsample(None, 2, 'nearest') (yolov8.yaml:759,764) and its adjoint (2x2 block sums)."""
 
