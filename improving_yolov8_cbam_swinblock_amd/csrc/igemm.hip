@@ -29,6 +29,8 @@
 //    (no atomics), (b) scale/bias/activation/residual.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 struct IgemmArgs {
@@ -45,34 +47,48 @@ struct IgemmArgs {
     int s_in, s_out, oh_off, ow_off;
     int Cout, cpt, ntaps, KC;
     uint64_t tap_dh, tap_dw;
-    int act, vec_store;
+    int act, vec_store, vec16;
+    uint32_t wo_mul, wo_shr, ho_mul, ho_shr;  // fast division by Wo / Ho
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// n / d for n < 2^31 with a host-computed magic (d == 1 <=> mul == 0)
+__device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t shr, int d) {
+    (void)d;
+    return mul ? (int)(__umulhi((uint32_t)n, mul) >> shr) : n;
+}
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
-    // one K step (64 B per row) = one 16x16x32 MFMA per tile pair
-    template <int TM, int TN>
+    // one K step = CPR 16-byte chunks per row = CPR/4 16x16x32 MFMAs per tile pair.
+    // swizzle: 64-B rows  -> chunk ^ ((-(row>>2))&3)   (rows r, r+4 share banks)
+    //          128-B rows -> chunk ^ ((row>>1)&7)      (rows r, r+2 share banks); both are conflict-free for the
+    //          4x16-lane groups of ds_read_b128 when a fragment's 16 rows start at a multiple of 16.
+    template <int TM, int TN, int CPR>
     static __device__ __forceinline__ void step(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM]) {
+        constexpr int ROWB = CPR * 16;
         const int l15 = lane & 15, l4 = lane >> 4;
-        const int sw = (-(l15 >> 2)) & 3;  // g(q) = (-q)&3: conflict-free for the 4x16-lane groups of ds_read_b128
-        const int coff = ((l4 ^ sw) << 4);
-        bf16x8 wf[TN], xf[TM];
+        const int sw = CPR == 4 ? ((-(l15 >> 2)) & 3) : ((l15 >> 1) & 7);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const bf16x8*>(Bs + (b_row0 + tn * 16 + l15) * 64 + coff);
+        for (int ks = 0; ks < CPR / 4; ++ks) {
+            const int coff = (((4 * ks + l4) ^ sw) << 4);
+            bf16x8 wf[TN], xf[TM];
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const bf16x8*>(As + (a_row0 + tm * 16 + l15) * 64 + coff);
+            for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const bf16x8*>(Bs + (b_row0 + tn * 16 + l15) * ROWB + coff);
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn)
+            for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const bf16x8*>(As + (a_row0 + tm * 16 + l15) * ROWB + coff);
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+        }
     }
 };
 template <> struct Mma<float> {
-    // one K step = 16 floats per row = four 16x16x4 f32 MFMAs per tile pair
-    template <int TM, int TN>
+    // one K step = 16 floats per row = four 16x16x4 f32 MFMAs per tile pair (64-byte rows only)
+    template <int TM, int TN, int CPR>
     static __device__ __forceinline__ void step(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM]) {
         const int l15 = lane & 15, l4 = lane >> 4;
         const int sw = (-(l15 >> 2)) & 3;  // g(q) = (-q)&3: conflict-free for the 4x16-lane groups of ds_read_b128
@@ -93,12 +109,15 @@ template <> struct Mma<float> {
 };
 
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, bool FAST, bool STATS>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS>
 __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
-    constexpr int NA = (BM * 4 + 255) / 256, NB = (BN * 4 + 255) / 256;
-    constexpr int STAGE = (BM + BN) * 64;
+    constexpr int ROWB = CPR * 16;                    // bytes per LDS row = K step per row (64: 32 bf16 / 16 f32; 128: 64 bf16)
+    constexpr int RPI = 256 / CPR, RPW = 64 / CPR;    // rows filled per block-wide / per wave load instruction
+    constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
+    constexpr int STAGE = (BM + BN) * ROWB;
+    static_assert(CPR == 4 || (CPR == 8 && FAST), "128-byte rows need tap-uniform K steps");
     static_assert(WM * WN == 4, "4 waves");
     static_assert(BM % 64 == 0, "every wave issues all A loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,19 +139,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     const T* zero = reinterpret_cast<const T*>(a.zero);
 
     // ---- per-thread load descriptors -----------------------------------------------------------
-    const int c = (tid & 3) ^ ((-(tid >> 4)) & 3);  // source chunk (0..3) of the K step this thread fetches (swizzle)
+    // source chunk of the K step this thread fetches: LDS position (row, tid % CPR) holds chunk pos ^ f(row)
+    const int c = CPR == 4 ? ((tid & 3) ^ ((-(tid >> 4)) & 3)) : ((tid & 7) ^ ((tid >> 4) & 7));
     int a_nH[NA], a_h[NA], a_w[NA];
     bool a_ok[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int r = (tid >> 2) + 64 * i;
+        const int r = tid / CPR + RPI * i;
         const int m = m0 + r;
         a_ok[i] = (m < a.M);
         const int mm = a_ok[i] ? m : 0;
-        const int wo = mm % a.Wo;
-        const int t = mm / a.Wo;
-        const int ho = t % a.Ho;
-        const int n = t / a.Ho;
+        const int t = fast_div(mm, a.wo_mul, a.wo_shr, a.Wo);
+        const int wo = mm - t * a.Wo;
+        const int n = fast_div(t, a.ho_mul, a.ho_shr, a.Ho);
+        const int ho = t - n * a.Ho;
         a_nH[i] = n * a.H;
         a_h[i] = ho * a.s_in;
         a_w[i] = wo * a.s_in;
@@ -141,7 +161,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     bool b_ok[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int rn = (tid >> 2) + 64 * j;
+        const int rn = tid / CPR + RPI * j;
         const int n = n0 + rn;
         b_ok[j] = (n < a.Cout) && (rn < BN);
         b_ptr[j] = wg + (int64_t)(b_ok[j] ? n : 0) * a.ktot;
@@ -153,46 +173,52 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     int tap = FAST ? 0 : c / a.cpt;
     int cic = FAST ? c : c - tap * a.cpt;
     const int adv_tap = 4 / a.cpt, adv_c = 4 - adv_tap * a.cpt;
-    const T* a_base[NA];
-    bool a_in[NA];
+    // FAST state: one running pointer + one per-step increment per row.  Rows whose tap falls outside the image
+    // (or outside M) point at the zero page with increment 0, so the K loop has no selects and no flags.
+    const T* a_ptr[NA];
+    int a_inc[NA];
+    const int steps_per_tap = a.cpt / CPR;  // scalar
+    int tap_s = 0, left = steps_per_tap;     // scalar (kernel arguments and loop counters only)
     auto setup_tap = [&](int tp) {
         const int dh = (int)((a.tap_dh >> (4 * tp)) & 15) - 8;
         const int dw = (int)((a.tap_dw >> (4 * tp)) & 15) - 8;
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int hi = a_h[i] + dh, wi = a_w[i] + dw;
-            a_in[i] = a_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            a_base[i] = xg + ((int64_t)(a_nH[i] + hi) * a.W + wi) * a.ldx;
+            const bool in = a_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            a_ptr[i] = in ? xg + ((int64_t)(a_nH[i] + hi) * a.W + wi) * a.ldx + c * CH : zero;
+            a_inc[i] = in ? CPR * CH : 0;
         }
     };
+    int b_inc[NB];
     if (FAST) {
         setup_tap(0);
 #pragma unroll
-        for (int j = 0; j < NB; ++j) b_ptr[j] += c * CH;
+        for (int j = 0; j < NB; ++j) {
+            b_ptr[j] = b_ok[j] ? b_ptr[j] + c * CH : zero;
+            b_inc[j] = b_ok[j] ? CPR * CH : 0;
+        }
     }
 
     auto issue = [&](int s) {
         char* As = smem + s * STAGE;
-        char* Bs = As + BM * 64;
+        char* Bs = As + BM * ROWB;
         if constexpr (FAST) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const T* src = a_in[i] ? a_base[i] + cic * CH : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                a_ptr[i] += a_inc[i];
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if ((wave * 16 + 64 * j) < BN) {  // wave-uniform
-                    const T* src = b_ok[j] ? b_ptr[j] : zero;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
-                    b_ptr[j] += 4 * CH;
+                if ((wave * RPW + RPI * j) < BN) {  // wave-uniform
+                    __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[j], (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+                    b_ptr[j] += b_inc[j];
                 }
             }
-            cic += 4;
-            if (cic >= a.cpt) {  // next tap (uniform: Cin is a multiple of the K step)
-                cic -= a.cpt;
-                ++tap;
-                if (tap < a.ntaps) setup_tap(tap);
+            if (--left == 0) {  // next tap (scalar branch)
+                left = steps_per_tap;
+                if (++tap_s < a.ntaps) setup_tap(tap_s);
             }
         } else {
             const bool kvalid = tap < a.ntaps;
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
-                if ((wave * 16 + 64 * j) < BN) {  // wave-uniform
+                if ((wave * RPW + RPI * j) < BN) {  // wave-uniform
                     const bool ok = b_ok[j] && kvalid;
                     const T* src = ok ? b_ptr[j] + (int64_t)(tap * a.cpt + cic) * CH : zero;
                     __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
@@ -231,8 +257,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     // loads this wave issues per K step (vmcnt counts LDS-DMA operations per wave, in order)
     constexpr int LPT_FULL = NA + NB;
     constexpr int LPT_AONLY = NA;  // waves beyond the B tile's rows (BN < 64) issue no B loads
-    const bool b_wave = (BN >= 64) || (wave * 16 < BN);
-    const int nkt = (a.KC + 3) >> 2;
+    const bool b_wave = (BN >= RPI) || (wave * RPW < BN);
+    const int nkt = (a.KC + CPR - 1) / CPR;
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nkt) issue(s);
@@ -247,57 +273,87 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
         // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
         if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
         const char* As = smem + (kt % NS) * STAGE;
-        Mma<T>::template step<TM, TN>(As, As + BM * 64, wm * TM * 16, wn * TN * 16, lane, acc);
+        Mma<T>::template step<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
 
     // ---- epilogue -----------------------------------------------------------------------------
+    // The tile leaves through LDS: lanes drop their 4-channel groups into a [pixel][channel] image, then the
+    // workgroup stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines
+    // (per-lane 8-byte stores to 16 different rows cost 2-3x the time of the same bytes stored this way).
     const int l15 = lane & 15, l4 = lane >> 4;
     T* __restrict__ yg = reinterpret_cast<T*>(a.y);
-    int64_t yoff[TM];
-    bool mok[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int m = m0 + (wm * TM + tm) * 16 + l15;
-        mok[tm] = m < a.M;
-        const int mm = mok[tm] ? m : 0;
-        if (a.s_out == 1 && a.Hy == a.Ho && a.Wy == a.Wo) {
-            yoff[tm] = (int64_t)mm * a.ldy;
-        } else {
-            const int wo = mm % a.Wo;
-            const int t = mm / a.Wo;
-            const int ho = t % a.Ho;
-            const int n = t / a.Ho;
-            yoff[tm] = (((int64_t)n * a.Hy + ho * a.s_out + a.oh_off) * a.Wy + wo * a.s_out + a.ow_off) * a.ldy;
-        }
-    }
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CROW = BN * ES + 16;  // padded LDS row of the output image
+    char* Cimg = smem;
+    float* red = reinterpret_cast<float*>(smem + BM * CROW);  // [WM][2][BN] (STATS)
+    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
 
-    if constexpr (STATS) {
-        float* red = reinterpret_cast<float*>(smem);  // [WM][2][BN]
+    auto out_offset = [&](int m) -> int64_t {
+        if (a.s_out == 1 && a.Hy == a.Ho && a.Wy == a.Wo) return (int64_t)m * a.ldy;
+        const int t = fast_div(m, a.wo_mul, a.wo_shr, a.Wo);
+        const int wo = m - t * a.Wo;
+        const int n = fast_div(t, a.ho_mul, a.ho_shr, a.Ho);
+        const int ho = t - n * a.Ho;
+        return (((int64_t)n * a.Hy + ho * a.s_out + a.oh_off) * a.Wy + wo * a.s_out + a.ow_off) * a.ldy;
+    };
+
 #pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int chl = (wn * TN + tn) * 16 + 4 * l4;  // channel within block tile
-            const int ch = n0 + chl;
-            float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int tn = 0; tn < TN; ++tn) {
+        const int chl = (wn * TN + tn) * 16 + 4 * l4;  // channel within the block tile
+        const int ch = n0 + chl;
+        float sc[4], bi[4];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!STATS) {
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                float v[4];
+            for (int r = 0; r < 4; ++r) {
+                const bool cok = ch + r < a.Cout;
+                sc[r] = (a.scale && cok) ? a.scale[ch + r] : 1.0f;
+                bi[r] = (a.bias && cok) ? a.bias[ch + r] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = (wm * TM + tm) * 16 + l15;
+            const int m = m0 + row;
+            float v[4];
+            if constexpr (STATS) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     v[r] = to_f32(from_f32<T>(acc[tn][tm][r]));  // statistics of what is stored
                     s1[r] += v[r];
                     s2[r] += v[r] * v[r];
                 }
-                if (mok[tm]) {
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(acc[tn][tm][r] * sc[r] + bi[r], a.act);
+                if (rg && m < a.M) {
                     if (a.vec_store && ch + 3 < a.Cout) {
-                        Pack<T, 4>::store(yg + yoff[tm] + ch, v);
+                        float rr[4];
+                        Pack<T, 4>::load(rg + (int64_t)m * a.ldres + ch, rr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (ch + r < a.Cout) yg[yoff[tm] + ch + r] = from_f32<T>(v[r]);
+                            if (ch + r < a.Cout) v[r] += to_f32(rg[(int64_t)m * a.ldres + ch + r]);
                     }
                 }
             }
+            if (a.vec16) {
+                Pack<T, 4>::store(reinterpret_cast<T*>(Cimg + row * CROW) + chl, v);
+            } else if (m < a.M) {  // unaligned / odd channel counts: direct stores
+                const int64_t yo = out_offset(m);
+                if (a.vec_store && ch + 3 < a.Cout) {
+                    Pack<T, 4>::store(yg + yo + ch, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ch + r < a.Cout) yg[yo + ch + r] = from_f32<T>(v[r]);
+                }
+            }
+        }
+        if constexpr (STATS) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -314,52 +370,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
                 }
             }
         }
-        __syncthreads();
+    }
+    __syncthreads();
+    if constexpr (STATS) {
         if (tid < 2 * BN) {
             const int which = tid / BN, chl = tid % BN;
-            float s = 0.f;
+            float sum = 0.f;
 #pragma unroll
-            for (int q = 0; q < WM; ++q) s += red[(q * 2 + which) * BN + chl];
+            for (int q = 0; q < WM; ++q) sum += red[(q * 2 + which) * BN + chl];
             const int ch = n0 + chl;
-            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.Cout + ch] = s;
+            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.Cout + ch] = sum;
         }
-    } else {
-        const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
-#pragma unroll
-        for (int tn = 0; tn < TN; ++tn) {
-            const int ch = n0 + (wn * TN + tn) * 16 + 4 * l4;
-            float sc[4], bi[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool cok = ch + r < a.Cout;
-                sc[r] = (a.scale && cok) ? a.scale[ch + r] : 1.0f;
-                bi[r] = (a.bias && cok) ? a.bias[ch + r] : 0.0f;
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                if (!mok[tm]) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(acc[tn][tm][r] * sc[r] + bi[r], a.act);
-                if (a.vec_store && ch + 3 < a.Cout) {
-                    if (rg) {
-                        float rr[4];
-                        const int m = m0 + (wm * TM + tm) * 16 + l15;
-                        Pack<T, 4>::load(rg + (int64_t)m * a.ldres + ch, rr);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                    }
-                    Pack<T, 4>::store(yg + yoff[tm] + ch, v);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        if (ch + r < a.Cout) {
-                            float o = v[r];
-                            if (rg) o += to_f32(rg[(int64_t)(m0 + (wm * TM + tm) * 16 + l15) * a.ldres + ch + r]);
-                            yg[yoff[tm] + ch + r] = from_f32<T>(o);
-                        }
-                    }
-                }
+    }
+    if (a.vec16) {
+        constexpr int CPW = BN * ES / 16;  // 16-byte chunks per output row
+        constexpr int EPC = 16 / ES;       // elements per chunk
+#pragma unroll 4
+        for (int idx = tid; idx < BM * CPW; idx += 256) {
+            const int row = idx / CPW, cc = idx % CPW;
+            const int m = m0 + row, ch = n0 + cc * EPC;
+            if (m < a.M && ch < a.Cout) {
+                const u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
+                *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
             }
         }
     }
@@ -381,25 +413,30 @@ static TileChoice choose_tile(int64_t M, int64_t cout) {
     return t;
 }
 
-// LDS ring depth: tuning knob YMI_IGEMM_NS (2..4).  Measured on the model's shapes: deeper rings cost occupancy
-// (the kernel is bound by the L1/TA path, not by latency), see DESIGN.md.
+// Row width of the LDS operand images: 128-byte rows (K step = 64 bf16) whenever Cin allows it: every LDS-DMA
+// instruction then touches 8 full 128-byte cache lines instead of 16 half lines, and there is one barrier per
+// 32 MFMAs per wave instead of per 16.  YMI_IGEMM_ROWB=64 forces the narrow form (tuning knob).
 template <typename T, bool STATS>
 static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) {
     dim3 grid((a.M + t.bm - 1) / t.bm, (a.Cout + t.bn - 1) / t.bn);
     const bool fast = (a.cpt % 4) == 0;
-    static const int ns_env = getenv("YMI_IGEMM_NS") ? atoi(getenv("YMI_IGEMM_NS")) : 0;
-    const int ns = ns_env >= 2 && ns_env <= 4 ? ns_env : 2;
-    const size_t lds = (size_t)ns * (t.bm + t.bn) * 64;
-#define YMI_LAUNCH2(BM, BN, WM, WN, NS)                                                                                    \
-    do {                                                                                                                   \
-        if (fast) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, true, STATS>), grid, dim3(256), lds, stream, a); \
-        else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, NS, false, STATS>), grid, dim3(256), lds, stream, a);     \
+    static const int rowb_env = getenv("YMI_IGEMM_ROWB") ? atoi(getenv("YMI_IGEMM_ROWB")) : 0;
+    const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0 && rowb_env != 64;
+    size_t lds = (size_t)2 * (t.bm + t.bn) * (wide ? 128 : 64);
+    const size_t epi = (size_t)t.bm * (t.bn * sizeof(T) + 16) + (STATS ? 4 * 2 * t.bn * sizeof(float) : 0);
+    if (epi > lds) lds = epi;
+#define YMI_LAUNCH1(KERNEL)                                                                                          \
+    do {                                                                                                             \
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(KERNEL, grid, dim3(256), lds, stream, a);                                                  \
     } while (0)
-#define YMI_LAUNCH(BM, BN, WM, WN)                     \
-    do {                                               \
-        if (ns == 2) YMI_LAUNCH2(BM, BN, WM, WN, 2);   \
-        else if (ns == 3) YMI_LAUNCH2(BM, BN, WM, WN, 3); \
-        else YMI_LAUNCH2(BM, BN, WM, WN, 4);           \
+#define YMI_LAUNCH(BM, BN, WM, WN)                                                              \
+    do {                                                                                        \
+        if constexpr (std::is_same<T, bf16_t>::value) {                                         \
+            if (wide) { YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS>)); break; } \
+        }                                                                                       \
+        if (fast) YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, true, STATS>));            \
+        else YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, false, STATS>));                \
     } while (0)
     if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2);
     else if (t.bm == 128 && t.bn == 64) YMI_LAUNCH(128, 64, 2, 2);
@@ -411,7 +448,7 @@ static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) 
         return YMI_EINVAL;
     }
 #undef YMI_LAUNCH
-#undef YMI_LAUNCH2
+#undef YMI_LAUNCH1
     YMI_CHECK_LAUNCH("igemm");
     return YMI_OK;
 }
@@ -430,6 +467,23 @@ int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks
     else rc = stats ? launch_igemm_t<float, true>(a, t, stream) : launch_igemm_t<float, false>(a, t, stream);
     ymi_prof_stop(stream, prof);
     return rc;
+}
+
+static void find_divisor(int d, uint32_t* mul, uint32_t* shr) {
+    if (d <= 1) { *mul = 0; *shr = 0; return; }
+    int lg = 0;
+    while ((1 << lg) < d) ++lg;
+    const int p = 31 + lg;
+    *mul = (uint32_t)(((1ull << p) + (uint64_t)d - 1) / (uint64_t)d);
+    *shr = (uint32_t)(p - 32);
+}
+static void finish_args(IgemmArgs& a, const ymi_tensor* y, const ymi_tensor* residual) {
+    find_divisor(a.Wo, &a.wo_mul, &a.wo_shr);
+    find_divisor(a.Ho, &a.ho_mul, &a.ho_shr);
+    const size_t es = ymi_esize(y->dtype);
+    const int epc = (int)(16 / es);
+    a.vec16 = a.vec_store && (y->ld % epc == 0) && (((uintptr_t)y->data) % 16 == 0) && (a.Cout % epc == 0);
+    (void)residual;
 }
 
 static void pack_taps(const int* dh, const int* dw, int n, uint64_t* pdh, uint64_t* pdw) {
@@ -480,6 +534,7 @@ extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t
     const int g = 4;
     a.vec_store = (y->ld % g == 0) && (((uintptr_t)y->data) % (g * ymi_esize(y->dtype)) == 0) &&
                   (!residual || (residual->ld % g == 0 && ((uintptr_t)residual->data) % (g * ymi_esize(y->dtype)) == 0));
+    finish_args(a, y, residual);
     int blocks = 0;
     int rc = ymi_launch_igemm(a, x->dtype, stat_partials != nullptr, &blocks, (hipStream_t)stream);
     if (host_stat_blocks) *host_stat_blocks = blocks;
@@ -527,6 +582,7 @@ extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_pac
             pack_taps(dh, dw, nt, &a.tap_dh, &a.tap_dw);
             a.act = YMI_ACT_NONE;
             a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0);
+            finish_args(a, dx, nullptr);
             int rc = ymi_launch_igemm(a, dy->dtype, false, nullptr, (hipStream_t)stream);
             if (rc) return rc;
         } else if (ho > 0 && wo > 0) {
