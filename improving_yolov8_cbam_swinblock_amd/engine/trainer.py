@@ -48,15 +48,47 @@ class TrainStep:
     """one optimisation step: forward under autocast, loss.sum() * world (reference trainer.py:386-388), backward
     with bucketed RCCL mean, unscale-free clip (bf16 needs no GradScaler), optimizer step, zero_grad."""
 
-    def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20):
+    def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20, graph=False):
         self.model = model
         self.world = world_size
         self.dtype = dtype
         self.opt = build_optimizer(model, lr=lr)
         self.buckets = GradientBuckets(model, world_size, bucket_bytes)
         self.params = [p for p in model.parameters() if p.requires_grad]
+        # graph=True: the whole step (forward, loss, backward, clip, update) is captured once into a HIP graph and
+        # replayed; every kernel of libyolo_mi355 only enqueues on the stream it is given, so the capture is legal.
+        # Needs static shapes: batch["max_boxes"] must be set.  Single-rank only (RCCL work stays eager).
+        self.use_graph = bool(graph) and world_size == 1
+        self._graph = None
+        self._static = None
+        self._static_items = None
 
     def __call__(self, batch):
+        if not self.use_graph:
+            return self.eager_step(batch)
+        if self._graph is None:
+            if batch.get("max_boxes") is None:
+                raise ValueError("graph=True needs batch['max_boxes'] (static target shape)")
+            # The first batch's tensors become the graph's static inputs (later batches are copied into them).
+            self._static = dict(batch)
+            # Warm-up (allocator, lazy state, workspaces) on the CURRENT stream.  Measured on ROCm 7.0 / torch 2.10:
+            # warming up on a side stream, as the CUDA recipe suggests, left the caching allocator handing the
+            # graph's private-pool blocks to later eager allocations (corrupted replays at bs >= 16); with the
+            # warm-up on the current stream replays stay isolated (tools/graph_probe.py).
+            for _ in range(3):
+                self.eager_step(self._static)
+            torch.cuda.synchronize()
+            self._graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._graph):
+                self._static_items = self.eager_step(self._static)
+        else:
+            for k, v in batch.items():
+                if torch.is_tensor(v) and v is not self._static[k]:
+                    self._static[k].copy_(v)
+        self._graph.replay()
+        return self._static_items
+
+    def eager_step(self, batch):
         self.model.train()
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             loss, items = self.model(batch)

@@ -102,6 +102,19 @@ class v8DetectionLoss:
         self.assigner = TaskAlignedAssigner(topk=tal_topk, num_classes=self.nc, alpha=0.5, beta=6.0)
         self.proj = torch.arange(det.reg_max, dtype=torch.float, device=self.device)
         self.gains = torch.tensor([self.hyp.box, self.hyp.cls, self.hyp.dfl], dtype=torch.float, device=self.device)
+        self.stride_list = [float(v) for v in det.stride]  # host copy: no device->host reads on the step path
+        self._geom = {}  # (level shapes) -> (anchor_points, stride_tensor, xyxy scale); built once, graph-capture safe
+
+    def geometry(self, feats):
+        key = tuple(tuple(f.shape[2:]) for f in feats)
+        g = self._geom.get(key)
+        if g is None:
+            anchor_points, stride_tensor = make_anchors(feats, self.stride_list, 0.5)
+            h, w = feats[0].shape[2:]
+            s0 = self.stride_list[0]
+            scale = torch.tensor([w * s0, h * s0, w * s0, h * s0], dtype=torch.float, device=self.device)
+            g = self._geom[key] = (anchor_points, stride_tensor, scale)
+        return g
 
     def preprocess(self, batch_idx, cls, bboxes, batch_size, scale, max_boxes=None):
         """ragged (img, cls, xywh-normalised) rows -> dense [B, nmax, 5] (cls, xyxy pixels), no Python loop."""
@@ -110,8 +123,8 @@ class v8DetectionLoss:
         if n == 0:
             return torch.zeros(batch_size, 0, 5, device=dev)
         img = batch_idx.to(dev).long().view(-1)
-        counts = torch.bincount(img, minlength=batch_size)
-        nmax = int(counts.max()) if max_boxes is None else int(max_boxes)
+        counts = torch.zeros(batch_size, dtype=torch.long, device=dev).scatter_add_(0, img, torch.ones_like(img))
+        nmax = int(counts.max()) if max_boxes is None else int(max_boxes)  # pass batch["max_boxes"] to avoid this host sync
         order = torch.argsort(img, stable=True)
         starts = torch.cumsum(counts, 0) - counts
         pos = torch.arange(n, device=dev) - starts[img[order]]
@@ -138,11 +151,9 @@ class v8DetectionLoss:
             pred_distri, pred_scores = cat.split((self.reg_max * 4, self.nc), 1)
             pred_scores = pred_scores.permute(0, 2, 1).contiguous()
             pred_distri = pred_distri.permute(0, 2, 1).contiguous()
-        stride = self.stride.to(dev)
-        imgsz = torch.tensor(feats[0].shape[2:], device=dev, dtype=torch.float) * stride[0]
-        anchor_points, stride_tensor = make_anchors(feats, stride, 0.5)
+        anchor_points, stride_tensor, scale = self.geometry(feats)
 
-        targets = self.preprocess(batch["batch_idx"], batch["cls"], batch["bboxes"], B, imgsz[[1, 0, 1, 0]], batch.get("max_boxes"))
+        targets = self.preprocess(batch["batch_idx"], batch["cls"], batch["bboxes"], B, scale, batch.get("max_boxes"))
         gt_labels, gt_bboxes = targets.split((1, 4), 2)
         mask_gt = gt_bboxes.sum(2, keepdim=True).gt(0.0).float()
 
