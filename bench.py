@@ -27,7 +27,7 @@ GFLOP_PER_IMG_FWD_BWD = 103.87  # SURVEY.md section 8(d), measured on the refere
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(batch=2, iters=4):
+def cpu_baseline(batch=4, iters=8):
     """reference's CPU path as restated by the oracle: fwd + v8 loss + bwd, fp32, all host cores."""
     from oracle.loss import v8DetectionLoss
     from oracle.tasks import DetectionModel

@@ -10,6 +10,8 @@
 // the reference's OIHW layout.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream);
@@ -38,13 +40,25 @@ constexpr int WG_BN = 128;   // cols  ((tap, ci))
 constexpr int WG_BK = 32;    // pixels per K step
 
 template <typename T> struct WFrag;
+// LDS bank swizzle for the transposed reads (bf16).  ds_read_b64_tr_b16 is serviced per 32-lane half: 2 groups x
+// (4 rows x 4 eight-byte units); the 8 rows of a half are {r0..r0+3, r0+8..r0+11}.  With 128-byte (dY) or 256-byte
+// (X) rows those rows share banks (4-way / 8-way conflict on the plain image), so the 8-byte unit index is XORed
+// with a per-row value that spreads the 8 rows over the 32 unit slots of a 256-byte bank row.  The XOR never touches
+// bit 0 of the unit index, so it is a permutation of 16-byte chunks and can be applied to the LDS-DMA SOURCE address.
+__device__ __forceinline__ int wg_swz_y(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }        // 2 bits
+__device__ __forceinline__ int wg_swz_x(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }                // 3 bits
+
 template <> struct WFrag<bf16_t> {
     // fragment of 8 k-values (pixels 8g..8g+7) for column c0+i of a [pixel][col] LDS image with `rowb` bytes per row
+    template <bool XIMG>
     static __device__ __forceinline__ bf16x8 load(const char* img, int rowb, int c0, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-        const char* a0 = img + (8 * g + q) * rowb + (c0 + 4 * p) * 2;
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * rowb));
+        const int r_lo = 8 * g + q, r_hi = r_lo + 4;
+        const int u = (c0 >> 2) + p;  // logical 8-byte unit of this lane's 4 columns
+        const int u_lo = u ^ ((XIMG ? wg_swz_x(r_lo) : wg_swz_y(r_lo)) << 2);
+        const int u_hi = u ^ ((XIMG ? wg_swz_x(r_hi) : wg_swz_y(r_hi)) << 2);
+        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + r_lo * rowb + u_lo * 8));
+        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + r_hi * rowb + u_hi * 8));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
@@ -53,9 +67,9 @@ template <> struct WFrag<bf16_t> {
     static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
         bf16x8 af[TR], bfr[TC];
 #pragma unroll
-        for (int t = 0; t < TR; ++t) af[t] = load(Ys, WG_BM * 2, r0 + t * 16, lane);
+        for (int t = 0; t < TR; ++t) af[t] = load<false>(Ys, WG_BM * 2, r0 + t * 16, lane);
 #pragma unroll
-        for (int t = 0; t < TC; ++t) bfr[t] = load(Xs, WG_BN * 2, c0 + t * 16, lane);
+        for (int t = 0; t < TC; ++t) bfr[t] = load<true>(Xs, WG_BN * 2, c0 + t * 16, lane);
 #pragma unroll
         for (int a = 0; a < TR; ++a)
 #pragma unroll
@@ -102,11 +116,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
     const T* __restrict__ yg = reinterpret_cast<const T*>(a.dy);
     const T* zero = reinterpret_cast<const T*>(a.zero);
 
-    // dY loader: thread -> (row, chunk) ; chunk column fixed per thread
-    const int ycc = tid % YCW;
+    // dY loader: thread -> (row, chunk) ; chunk column fixed per thread.  bf16: LDS position (row, chunk') holds
+    // source chunk chunk' ^ (swizzle(row) << 1); the row bits the swizzle uses are the same for all of a thread's rows.
+    constexpr bool SWZ = std::is_same<T, bf16_t>::value;
+    const int ycc = SWZ ? ((tid % YCW) ^ (wg_swz_y(tid / YCW) << 1)) : (tid % YCW);
     const bool y_cok = co0 + ycc * CH < a.CoutP;
     // X loader: column chunk fixed per thread -> fixed tap / input-channel offset
-    const int xcc = tid % XCW;
+    const int xcc = SWZ ? ((tid % XCW) ^ (wg_swz_x(tid / XCW) << 1)) : (tid % XCW);
     const int j = j0 + xcc * CH;
     const bool x_cok = j < a.NG;
     const int tap = x_cok ? j / a.Cin : 0;
