@@ -206,20 +206,39 @@ __global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
         }
 }
 
-// Slab reduction in two parallel stages (both deterministic):
-//  stage 1: grid (elements/256, R): group g sums slabs g, g+R, ... element-wise (coalesced) into stage[g][:]
-//  stage 2: dw[co][ci][kh][kw] = sum_g stage[g][co][tap*Cin + ci]   (scatter into OIHW)
-__global__ __launch_bounds__(256) void wgrad_stage_kernel(const float* __restrict__ slab, int splits, int64_t elems, int R, float* __restrict__ stage) {
-    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e >= elems) return;
-    const int g = blockIdx.y;
-    float s = 0.f;
-    for (int k = g; k < splits; k += R) s += slab[(int64_t)k * elems + e];
-    stage[(int64_t)g * elems + e] = s;
+// Slab reduction, one launch, deterministic: a 1024-thread workgroup owns 32 consecutive outputs (one 128-byte
+// row piece of every slab) and 32 split lanes; lane j sums splits j, j+32, ... in order, then the 32 lane sums are
+// added in lane order.  dw[co][ci][kh][kw] = sum_s slab[s][co][tap*Cin + ci]  (scatter into OIHW).
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real,
+                                                             int cin_real, int ntaps, float* __restrict__ dw) {
+    __shared__ float red[32][33];
+    const int ol = threadIdx.x & 31, lane = threadIdx.x >> 5;
+    const int64_t e = (int64_t)blockIdx.x * 32 + ol;  // element of the [CoutP][NG] slab
+    const int64_t elems = (int64_t)CoutP * NG;
+    float s0 = 0.f, s1 = 0.f;
+    if (e < elems) {
+        int k = lane;
+        for (; k + 32 < splits; k += 64) {  // two independent chains in flight
+            s0 += slab[(int64_t)k * elems + e];
+            s1 += slab[(int64_t)(k + 32) * elems + e];
+        }
+        if (k < splits) s0 += slab[(int64_t)k * elems + e];
+    }
+    red[lane][ol] = s0 + s1;
+    __syncthreads();
+    if (lane == 0 && e < elems) {
+        float s = 0.f;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) s += red[q][ol];
+        const int co = (int)(e / NG), col = (int)(e % NG);
+        const int tap = col / Cin, ci = col % Cin;
+        if (co < cout_real && ci < cin_real) dw[((int64_t)co * cin_real + ci) * ntaps + tap] = s;
+    }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real, int cin_real,
-                                    int ntaps, float* __restrict__ dw) {
+// few splits (large weight matrices): one thread per output element, coalesced along (tap, ci)
+__global__ void wgrad_reduce_small_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real, int cin_real,
+                                          int ntaps, float* __restrict__ dw) {
     const int64_t total = (int64_t)cout_real * ntaps * cin_real;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
         const int ci = (int)(idx % cin_real);
@@ -233,7 +252,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, 
     }
 }
 
-constexpr int WG_STAGE_R = 16;
+constexpr int WG_STAGE_R = 0;
 
 struct WgradPlan {
     int splits, pix_per_split;
@@ -306,20 +325,17 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     }
     ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");
-    const int64_t total = cout_real * kh * kw * cin_real;
-    int64_t gb = (total + 255) / 256;
-    if (gb > 2048) gb = 2048;
-    const float* red_src = a.slab;
-    int red_splits = p.splits;
-    if (p.splits > 2 * WG_STAGE_R) {
-        const int64_t elems = (int64_t)a.CoutP * a.NG;
-        float* stage = a.slab + (int64_t)p.splits * elems;
-        hipLaunchKernelGGL(wgrad_stage_kernel, dim3((unsigned)((elems + 255) / 256), WG_STAGE_R), dim3(256), 0, s, (const float*)a.slab, p.splits, elems, WG_STAGE_R, stage);
-        red_src = stage;
-        red_splits = WG_STAGE_R;
+    const int64_t elems = (int64_t)a.CoutP * a.NG;
+    if (p.splits > 32) {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(1024), 0, s, (const float*)a.slab, p.splits, a.CoutP,
+                           a.NG, a.Cin, (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
+    } else {
+        const int64_t total = cout_real * kh * kw * cin_real;
+        int64_t gb = (total + 255) / 256;
+        if (gb > 2048) gb = 2048;
+        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)gb), dim3(256), 0, s, (const float*)a.slab, p.splits, a.CoutP, a.NG, a.Cin,
+                           (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
     }
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)gb), dim3(256), 0, s, red_src, red_splits, a.CoutP, a.NG, a.Cin,
-                       (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
     YMI_CHECK_LAUNCH("wgrad_reduce");
     if (dbias) {
         // bias gradient: column sums of dy (first cout_real channels are the real ones)
