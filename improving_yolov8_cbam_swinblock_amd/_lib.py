@@ -56,6 +56,7 @@ _SIGNATURES = {
     "ymi_pack_conv_weight_dgrad": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _vp, _vp]),
     "ymi_pack_conv_weight_dgrad_ex": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _vp, _vp]),
     "ymi_conv_dgrad_pack_elems": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "ymi_pack_conv_weights_batch": (_c_i32, [_vp, _vp, _c_i32, _c_i32, _c_i32, _vp]),
     "ymi_pack_matrix": (_c_i32, [_vp, _c_i64, _c_i64, _c_i32, _c_i32, _vp, _vp]),
     "ymi_conv2d_fwd": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _c_i32, _TP, _TP, _vp, ctypes.POINTER(_c_i64), _vp]),
     "ymi_conv2d_stat_blocks": (_c_i64, [_c_i64, _c_i64]),

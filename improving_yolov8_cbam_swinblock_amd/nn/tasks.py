@@ -135,6 +135,7 @@ class BaseModel(nn.Module):
         """the 27-step module loop of reference tasks.py:152-179.  split_head: return Detect's maps before
         its channel concat (training loss fast path)."""
         y = []
+        self._begin_weight_arena(x)
         with ops.deferred_bn_counters():
             for m in self.model:
                 if m.f != -1:
@@ -144,6 +145,22 @@ class BaseModel(nn.Module):
                 x = m(x)
                 y.append(x if m.i in self.save else None)
         return x
+
+    def _begin_weight_arena(self, x):
+        """training forwards pack every weight with one launch (ops.WeightArena): the first forward+backward records
+        the uses, the second forward builds the arena; eval / no-grad forwards keep the per-call packers."""
+        if not (self.training and torch.is_grad_enabled() and x.is_cuda):
+            ops.set_weight_arena(None)
+            return
+        dt = ops.compute_dtype(x)
+        arena = getattr(self, "_arena", None)
+        if arena is None or (arena.dtype is not None and arena.dtype != dt):
+            arena = self._arena = ops.WeightArena()
+        elif not arena.built and arena.specs:
+            arena.build()
+        ops.set_weight_arena(arena)
+        if arena.built:
+            arena.pack()
 
     def fuse(self, verbose=False):
         """fold BN into conv for inference (reference tasks.py:210-238)."""

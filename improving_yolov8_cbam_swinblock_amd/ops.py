@@ -105,7 +105,95 @@ def to_nchw_float(x):
 
 
 # ------------------------------------------------------------------------------------ weights
+class _PackDesc(ctypes.Structure):
+    _fields_ = [("src", ctypes.c_void_p), ("dst_fwd", ctypes.c_void_p), ("dst_dgrad", ctypes.c_void_p), ("o", ctypes.c_int32),
+                ("i", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("ipad", ctypes.c_int32), ("opad", ctypes.c_int32),
+                ("stride", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+
+
+class WeightArena:
+    """All conv / linear weights of a model packed into kernel operand layouts by ONE launch per step.
+
+    Life cycle: while `recording`, the per-call packers below note (weight, padding, stride) of every use during one
+    full forward+backward; `build()` then allocates one arena and a device descriptor table; afterwards `pack()`
+    (called at the start of each training forward) refreshes every operand with a single kernel and the per-call
+    packers return views of the arena.  A use that was not recorded simply falls back to its own pack launch."""
+
+    def __init__(self):
+        self.specs = {}      # id(weight) -> dict(weight, o, i, k, ipad, opad, stride)
+        self.dtype = None
+        self.built = False
+        self.fresh = False   # operands correspond to the current weight values
+        self.views = {}
+
+    def note(self, weight, dtype, ipad=None, opad=None, stride=1):
+        if self.built:
+            return
+        w4 = _as4d(weight)
+        o, i, k, _ = w4.shape
+        sp = self.specs.setdefault(id(weight), dict(weight=weight, o=o, i=i, k=k, ipad=None, opad=None, stride=1))
+        if ipad is not None:
+            sp["ipad"] = ipad
+        if opad is not None:
+            sp["opad"], sp["stride"] = opad, stride
+        self.dtype = dtype
+
+    def build(self):
+        if not self.specs:
+            return
+        dev = next(iter(self.specs.values()))["weight"].device
+        es = 2 if self.dtype == torch.bfloat16 else 4
+        total, plan = 0, []
+        for key, sp in self.specs.items():
+            nf = sp["o"] * sp["k"] ** 2 * sp["ipad"] if sp["ipad"] else 0
+            nd = sp["i"] * sp["k"] ** 2 * sp["opad"] if sp["opad"] else 0
+            offf, total = total, total + round_up(nf, 8)
+            offd, total = total, total + round_up(nd, 8)
+            plan.append((key, sp, nf, nd, offf, offd))
+        self.arena = torch.empty(total, dtype=self.dtype, device=dev)
+        descs = (_PackDesc * len(plan))()
+        starts = [0]
+        base = self.arena.data_ptr()
+        for n, (key, sp, nf, nd, offf, offd) in enumerate(plan):
+            w = sp["weight"]
+            descs[n] = _PackDesc(w.data_ptr(), base + offf * es if nf else None, base + offd * es if nd else None, sp["o"], sp["i"], sp["k"],
+                                 sp["k"], sp["ipad"] or 0, sp["opad"] or 0, sp["stride"], 0)
+            starts.append(starts[-1] + (max(nf, nd) + 1023) // 1024)
+            self.views[key] = (self.arena[offf : offf + nf] if nf else None, self.arena[offd : offd + nd] if nd else None, sp["ipad"], sp["opad"], sp["stride"])
+        raw = bytes(descs)
+        self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        self.starts = torch.tensor(starts, dtype=torch.int32).to(dev)
+        self.count, self.blocks = len(plan), starts[-1]
+        self.params = [sp["weight"] for _, sp, *_ in plan]
+        self.built = True
+
+    def pack(self):
+        check(L().ymi_pack_conv_weights_batch(ptr(self.descs), ptr(self.starts), self.count, self.blocks, ymi_dtype(self.dtype), stream_ptr()), "pack_conv_weights_batch")
+        self.fresh = True
+
+    def lookup_fwd(self, weight, ipad, dtype):
+        v = self.views.get(id(weight)) if (self.built and self.fresh and dtype == self.dtype) else None
+        return v[0] if v is not None and v[0] is not None and v[2] == ipad else None
+
+    def lookup_dgrad(self, weight, opad, stride, dtype):
+        v = self.views.get(id(weight)) if (self.built and self.fresh and dtype == self.dtype) else None
+        return v[1] if v is not None and v[1] is not None and v[3] == opad and v[4] == stride else None
+
+
+_arena = None  # the WeightArena of the model whose forward/backward is running (set by DetectionModel)
+
+
+def set_weight_arena(arena):
+    global _arena
+    _arena = arena
+
+
 def pack_conv_fwd(weight, cin_pad, dtype):
+    if _arena is not None:
+        hit = _arena.lookup_fwd(weight, cin_pad, dtype)
+        if hit is not None:
+            return hit
+        _arena.note(weight, dtype, ipad=cin_pad)
     o, i, kh, kw = weight.shape
     buf = torch.empty(o * kh * kw * cin_pad, dtype=dtype, device=weight.device)
     check(L().ymi_pack_conv_weight_fwd(ptr(weight.detach()), o, i, kh, kw, cin_pad, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_fwd")
@@ -113,6 +201,11 @@ def pack_conv_fwd(weight, cin_pad, dtype):
 
 
 def pack_conv_dgrad(weight, cout_pad, stride, dtype):
+    if _arena is not None:
+        hit = _arena.lookup_dgrad(weight, cout_pad, stride, dtype)
+        if hit is not None:
+            return hit
+        _arena.note(weight, dtype, opad=cout_pad, stride=stride)
     o, i, kh, kw = weight.shape
     buf = torch.empty(cout_pad * i * kh * kw, dtype=dtype, device=weight.device)
     check(L().ymi_pack_conv_weight_dgrad_ex(ptr(weight.detach()), o, cout_pad, i, kh, kw, stride, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_dgrad")

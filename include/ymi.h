@@ -85,6 +85,17 @@ int ymi_pack_conv_weight_dgrad(const float* w_oihw, int64_t o, int64_t i, int64_
 /* same, with the K axis (dy channels) zero-padded from o_real to o_pad rows. */
 int ymi_pack_conv_weight_dgrad_ex(const float* w_oihw, int64_t o_real, int64_t o_pad, int64_t i, int64_t kh, int64_t kw, int64_t stride, int32_t dtype, void* dst, void* stream);
 int64_t ymi_conv_dgrad_pack_elems(int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t stride);
+/* All weights of a model in ONE launch.  descs_device: array of ymi_pack_desc in device memory; block_start_device:
+ * int32[count+1] prefix sums of ceil(max(fwd elems, dgrad elems)/1024) per tensor; either destination may be NULL.
+ * Same layouts as ymi_pack_conv_weight_fwd / _dgrad_ex (nn.Linear weights: kh = kw = 1). */
+typedef struct ymi_pack_desc {
+    const float* src;
+    void* dst_fwd;
+    void* dst_dgrad;
+    int32_t o, i, kh, kw, ipad, opad, stride, _pad;
+} ymi_pack_desc;
+int ymi_pack_conv_weights_batch(const void* descs_device, const int32_t* block_start_device, int32_t count, int32_t total_blocks,
+                                int32_t dtype, void* stream);
 /* [rows][cols] f32 -> `dtype`, optionally transposed ([cols][rows]): nn.Linear / in_proj weights. */
 int ymi_pack_matrix(const float* src, int64_t rows, int64_t cols, int32_t transpose, int32_t dtype, void* dst, void* stream);
 
