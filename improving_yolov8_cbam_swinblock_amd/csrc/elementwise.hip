@@ -265,18 +265,19 @@ extern "C" int ymi_pack_matrix(const float* src, int64_t rows, int64_t cols, int
 }
 
 // ------------------------------------------------------------------------------ BatchNorm pieces
-// One thread column per channel, 4 row-slices per block; sums in double so that the cross-block
-// reduction adds nothing to the error of the per-block f32 partials.
-__global__ void bn_finalize_kernel(const float* __restrict__ part, int blocks, double count, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar, float momentum,
-                                   float eps, float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
-                                   float* __restrict__ sinv) {
-    __shared__ double red[2][4][64];
-    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+// 32 channels x 32 row slices per 1024-thread block (short dependent chains: this kernel is pure latency);
+// sums in double so that the cross-block reduction adds nothing to the error of the per-block f32 partials.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int blocks, double count, int C,
+                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                           float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
+                                                           float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
+                                                           float* __restrict__ sinv) {
+    __shared__ double red[2][32][33];
+    const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int b = slice; b < blocks; b += 4) {
+        for (int b = slice; b < blocks; b += 32) {
             s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
             s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
         }
@@ -285,8 +286,13 @@ __global__ void bn_finalize_kernel(const float* __restrict__ part, int blocks, d
     red[1][slice][cl] = s2;
     __syncthreads();
     if (slice == 0 && c < C) {
-        s1 = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-        s2 = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+        s1 = 0.0;
+        s2 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            s1 += red[0][q][cl];
+            s2 += red[1][q][cl];
+        }
         const double mean = s1 / count;
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -336,14 +342,14 @@ extern "C" int ymi_bn_finalize(const float* part, int64_t blocks, int64_t count,
     YMI_CHECK_ARG(part && scale && shift && blocks > 0 && count > 0 && c > 0, "bn_finalize: args");
     const float* src = part;
     int rows = (int)blocks;
-    if (blocks > 4 * BN_STAGE_ROWS) {
+    if (blocks > 16 * BN_STAGE_ROWS) {
         float* stage = const_cast<float*>(part) + blocks * 2 * c;  // scratch rows after the partials
         hipLaunchKernelGGL(stat_rows_reduce_kernel, dim3((unsigned)((c + 63) / 64), BN_STAGE_ROWS), dim3(256), 0, (hipStream_t)stream, part,
                            (int)blocks, (int)c, BN_STAGE_ROWS, stage);
         src = stage;
         rows = BN_STAGE_ROWS;
     }
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 63) / 64)), dim3(256), 0, (hipStream_t)stream, src, rows,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, rows,
                        (double)count, (int)c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv);
     YMI_CHECK_LAUNCH("bn_finalize");
     return YMI_OK;

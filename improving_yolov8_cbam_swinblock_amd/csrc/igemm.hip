@@ -179,14 +179,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     int a_inc[NA];
     const int steps_per_tap = a.cpt / CPR;  // scalar
     int tap_s = 0, left = steps_per_tap;     // scalar (kernel arguments and loop counters only)
+    // per-row pointer of the tap-(0,0) pixel; a tap only adds the scalar (dh*W + dw)*ldx and re-tests the bounds
+    const T* a_center[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_center[i] = xg + ((int64_t)(a_nH[i] + a_h[i]) * a.W + a_w[i]) * a.ldx + c * CH;
     auto setup_tap = [&](int tp) {
         const int dh = (int)((a.tap_dh >> (4 * tp)) & 15) - 8;
         const int dw = (int)((a.tap_dw >> (4 * tp)) & 15) - 8;
+        const int64_t toff = ((int64_t)dh * a.W + dw) * a.ldx;  // scalar
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
-            const int hi = a_h[i] + dh, wi = a_w[i] + dw;
-            const bool in = a_ok[i] && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            a_ptr[i] = in ? xg + ((int64_t)(a_nH[i] + hi) * a.W + wi) * a.ldx + c * CH : zero;
+            const bool in = a_ok[i] && (unsigned)(a_h[i] + dh) < (unsigned)a.H && (unsigned)(a_w[i] + dw) < (unsigned)a.W;
+            a_ptr[i] = in ? a_center[i] + toff : zero;
             a_inc[i] = in ? CPR * CH : 0;
         }
     };

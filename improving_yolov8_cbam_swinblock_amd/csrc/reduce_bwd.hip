@@ -19,17 +19,18 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
     extern __shared__ float red[];  // [rows][TG][8]
     const int rows = 256 / TG;
     const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
-    const int groups = C / 4;
+    const int c0 = blockIdx.y * 1024;  // channels beyond 1024 go to further grid rows
+    const int groups = ((C - c0 < 1024) ? C - c0 : 1024) / 4;
     const int64_t per = (P + gridDim.x - 1) / gridDim.x;
     const int64_t p0 = blockIdx.x * per, p1 = (p0 + per < P) ? p0 + per : P;
-    const T* ap = reinterpret_cast<const T*>(a.p);
-    const T* bp = reinterpret_cast<const T*>(b.p);
+    const T* ap = reinterpret_cast<const T*>(a.p) + c0;
+    const T* bp = reinterpret_cast<const T*>(b.p) + c0;
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
     if (tx < groups) {
         float g[4], be[4], mu[4], iv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int c = tx * 4 + r;
+            const int c = c0 + tx * 4 + r;
             g[r] = (FN == 1 && gamma) ? gamma[c] : 1.0f;
             be[r] = (FN == 1 && beta) ? beta[c] : 0.0f;
             mu[r] = (FN == 1) ? mean[c] : 0.0f;
@@ -93,8 +94,8 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            part[((int64_t)blockIdx.x * 2 + 0) * C + tx * 4 + r] = s0[r];
-            part[((int64_t)blockIdx.x * 2 + 1) * C + tx * 4 + r] = s1[r];
+            part[((int64_t)blockIdx.x * 2 + 0) * C + c0 + tx * 4 + r] = s0[r];
+            part[((int64_t)blockIdx.x * 2 + 1) * C + c0 + tx * 4 + r] = s1[r];
         }
     }
 }
@@ -160,15 +161,16 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
                               const float* inv, int act, float* part, int* blocks_out, hipStream_t stream, const char* what) {
     const int64_t P = ymi_pixels(a);
     const int C = (int)a->c;
-    YMI_CHECK_ARG(C % 4 == 0 && a->ld % 4 == 0 && C <= 1024 && (!b || (b->ld % 4 == 0)), "%s: channels must be a multiple of 4 and <= 1024", what);
+    YMI_CHECK_ARG(C % 4 == 0 && a->ld % 4 == 0 && (!b || (b->ld % 4 == 0)), "%s: channels must be a multiple of 4", what);
     const int TG = pow2_ge(C / 4) > 256 ? 256 : pow2_ge(C / 4);
+    const int crows = (C + 1023) / 1024;
     const int blocks = reduce_blocks(P);
     const size_t lds = (size_t)256 * 8 * sizeof(float);
     RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
     if (a->dtype == YMI_BF16)
-        hipLaunchKernelGGL((chan_reduce_kernel<bf16_t, FN>), dim3(blocks), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
+        hipLaunchKernelGGL((chan_reduce_kernel<bf16_t, FN>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
     else
-        hipLaunchKernelGGL((chan_reduce_kernel<float, FN>), dim3(blocks), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
+        hipLaunchKernelGGL((chan_reduce_kernel<float, FN>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
     YMI_CHECK_LAUNCH(what);
     *blocks_out = blocks;
     return YMI_OK;
