@@ -72,6 +72,16 @@ def cpu_baseline(batch=4, iters=8):
     }
 
 
+def traffic_bytes(family):
+    """HBM bytes per launch of the kernel family from the committed PMC passes (tools/pmc_traffic.py); None if absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as fh:
+            return json.load(fh)["families"][family]["hbm_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,7 +145,9 @@ def main():
         ms = (ctypes.c_double * 2)()
         fl = (ctypes.c_double * 2)()
         cnt = (ctypes.c_int64 * 2)()
-        _lib.check(lib.ymi_profile_end(ms, fl, cnt), "profile_end")
+        byt = (ctypes.c_double * 2)()
+        bnd = (ctypes.c_double * 2)()
+        _lib.check(lib.ymi_profile_end_ex(ms, fl, cnt, byt, bnd), "profile_end_ex")
         fam = 0 if ms[0] >= ms[1] else 1
         names = ["igemm_kernel (implicit-GEMM conv fwd / dgrad / token GEMM)", "wgrad_kernel (weight-gradient split-K GEMM)"]
         ach = fl[fam] / (ms[fam] * 1e-3) / 1e12 if ms[fam] > 0 else 0.0
@@ -146,13 +158,20 @@ def main():
             "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": None,
+            "traffic": traffic_bytes(["igemm", "wgrad"][fam]),
+            "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01_pmc_traffic.json)",
+            "algorithmic_bytes_per_launch": round(byt[fam] / max(cnt[fam], 1)),
+            # every launch against ITS OWN roofline, max(flop / 2.5 PF, algorithmic bytes / 8 TB/s): the 1x1 and
+            # narrow convs of this model are HBM-bound, so the family's MFMA fraction alone understates them
+            "frac_of_per_launch_bounds": round(bnd[fam] / max(ms[fam], 1e-9), 4),
             "launches_per_step": cnt[fam] // max(prof_steps, 1),
             "avg_launch_us": round(ms[fam] * 1e3 / max(cnt[fam], 1), 2),
             "measured_over": "the timed steps" if instrument_inline else f"{prof_steps} eager steps right after the timed (graph-replayed) steps",
             "families": {
-                "igemm": {"ms_per_step": round(ms[0] / prof_steps, 3), "tflops": round(fl[0] / max(ms[0], 1e-9) / 1e9, 2)},
-                "wgrad": {"ms_per_step": round(ms[1] / prof_steps, 3), "tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 2)},
+                "igemm": {"ms_per_step": round(ms[0] / prof_steps, 3), "tflops": round(fl[0] / max(ms[0], 1e-9) / 1e9, 2),
+                          "frac_of_per_launch_bounds": round(bnd[0] / max(ms[0], 1e-9), 4)},
+                "wgrad": {"ms_per_step": round(ms[1] / prof_steps, 3), "tflops": round(fl[1] / max(ms[1], 1e-9) / 1e9, 2),
+                          "frac_of_per_launch_bounds": round(bnd[1] / max(ms[1], 1e-9), 4)},
             },
         }
     if world > 1:

@@ -46,6 +46,8 @@ _SIGNATURES = {
     "ymi_last_error": (ctypes.c_char_p, []),
     "ymi_profile_begin": (_c_i32, [_c_i64]),
     "ymi_profile_end": (_c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
+    "ymi_profile_end_ex": (_c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64),
+                                    ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
     "ymi_nchw_to_nhwc": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
     "ymi_nhwc_to_nchw": (_c_i32, [_TP, _vp, _vp]),
     "ymi_copy": (_c_i32, [_TP, _TP, _vp]),

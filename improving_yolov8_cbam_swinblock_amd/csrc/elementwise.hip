@@ -403,18 +403,29 @@ __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const 
     const T* xp = reinterpret_cast<const T*>(x.p);
     const T* rp = reinterpret_cast<const T*>(res.p);
     T* op = reinterpret_cast<T*>(o.p);
-    for (int64_t p = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / groups; p < P; p += (int64_t)gridDim.x * rows_per_block) {
-        float v[4];
-        Pack<T, 4>::load(xp + p * x.ld + g * 4, v);
+    auto one = [&](float (&v)[4], const float (&rr)[4], int64_t p) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT>(v[r] * sc[r] + sh[r]);
-        if (rp) {
-            float rr[4];
-            Pack<T, 4>::load(rp + p * res.ld + g * 4, rr);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-        }
+        for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT>(v[r] * sc[r] + sh[r]) + rr[r];
         Pack<T, 4>::store(op + p * o.ld + g * 4, v);
+    };
+    const int64_t step = (int64_t)gridDim.x * rows_per_block;
+    int64_t p = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / groups;
+    // 4 pixels per trip: the loads of all four are in flight before the first use
+    for (; p + 3 * step < P; p += 4 * step) {
+        float v[4][4], rr[4][4] = {};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            Pack<T, 4>::load(xp + (p + u * step) * x.ld + g * 4, v[u]);
+            if (rp) Pack<T, 4>::load(rp + (p + u * step) * res.ld + g * 4, rr[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) one(v[u], rr[u], p + u * step);
+    }
+    for (; p < P; p += step) {
+        float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};
+        Pack<T, 4>::load(xp + p * x.ld + g * 4, v);
+        if (rp) Pack<T, 4>::load(rp + p * res.ld + g * 4, rr);
+        one(v, rr, p);
     }
 }
 
@@ -424,7 +435,7 @@ static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const fl
     const int64_t P = ymi_pixels(raw);
     const int rows = 256 / groups;
     int64_t gb = (P + rows - 1) / rows;
-    if (gb > 256 * 16) gb = 256 * 16;
+    if (gb > 2048) gb = 2048;  // one resident round of 256-thread blocks on 256 CUs
     dim3 g((unsigned)gb), b(256);
     if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
     else if (act == YMI_ACT_GELU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_GELU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);

@@ -458,14 +458,19 @@ static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) 
 }
 
 bool ymi_prof_enabled();
-int ymi_prof_start(hipStream_t stream, int family, double flop);
+int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, double peak_tflops);
 void ymi_prof_stop(hipStream_t stream, int idx);
 
 int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
     TileChoice t = choose_tile(a.M, a.Cout);
     if (host_blocks) *host_blocks = (a.M + t.bm - 1) / t.bm;
     int prof = -1;
-    if (ymi_prof_enabled()) prof = ymi_prof_start(stream, 0, 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot);
+    if (ymi_prof_enabled()) {
+        const double es = dtype == YMI_BF16 ? 2.0 : 4.0;
+        const double in_pix = (double)a.M / ((double)a.Ho * a.Wo) * (double)a.H * a.W;  // the whole input map, read once
+        const double bytes = in_pix * a.cpt * 16.0 + (double)a.ktot * a.Cout * es + (double)a.M * a.Cout * es * (a.res ? 2.0 : 1.0);
+        prof = ymi_prof_start(stream, 0, 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot, bytes, dtype == YMI_BF16 ? 2500.0 : 157.3);
+    }
     int rc;
     if (dtype == YMI_BF16) rc = stats ? launch_igemm_t<bf16_t, true>(a, t, stream) : launch_igemm_t<bf16_t, false>(a, t, stream);
     else rc = stats ? launch_igemm_t<float, true>(a, t, stream) : launch_igemm_t<float, false>(a, t, stream);

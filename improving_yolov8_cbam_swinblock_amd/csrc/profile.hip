@@ -9,7 +9,7 @@ namespace {
 struct Rec {
     hipEvent_t e0, e1;
     int family;
-    double flop;
+    double flop, bytes, bound_ms;
 };
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -20,9 +20,12 @@ size_t g_next = 0;
 bool ymi_prof_enabled() { return g_on; }
 
 // returns an index to pass to ymi_prof_stop, or -1
-int ymi_prof_start(hipStream_t stream, int family, double flop) {
+// flop / bytes: the launch's algorithmic work and HBM traffic (operands read once, result written once);
+// peak_tflops: dense MFMA peak of the launch's dtype.  bound_ms = the launch's own roofline, max of the two.
+int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, double peak_tflops) {
     if (!g_on || g_next + 2 > g_pool.size()) return -1;
-    Rec r{g_pool[g_next], g_pool[g_next + 1], family, flop};
+    const double t_mfma = flop / (peak_tflops * 1e12) * 1e3, t_hbm = bytes / 8.0e12 * 1e3;
+    Rec r{g_pool[g_next], g_pool[g_next + 1], family, flop, bytes, t_mfma > t_hbm ? t_mfma : t_hbm};
     g_next += 2;
     (void)hipEventRecord(r.e0, stream);
     g_recs.push_back(r);
@@ -50,13 +53,16 @@ extern "C" int ymi_profile_begin(int64_t capacity) {
 }
 
 // family 0: implicit-GEMM conv (forward, data gradient, token GEMMs); family 1: weight-gradient GEMM
-extern "C" int ymi_profile_end(double* ms_by_family, double* flop_by_family, int64_t* launches_by_family) {
+extern "C" int ymi_profile_end_ex(double* ms_by_family, double* flop_by_family, int64_t* launches_by_family, double* bytes_by_family,
+                                  double* bound_ms_by_family) {
     g_on = false;
     YMI_CHECK_ARG(ms_by_family && flop_by_family && launches_by_family, "profile_end: null");
     for (int f = 0; f < 2; ++f) {
         ms_by_family[f] = 0.0;
         flop_by_family[f] = 0.0;
         launches_by_family[f] = 0;
+        if (bytes_by_family) bytes_by_family[f] = 0.0;
+        if (bound_ms_by_family) bound_ms_by_family[f] = 0.0;
     }
     if (hipDeviceSynchronize() != hipSuccess) {
         ymi_set_error("profile_end: device synchronize failed");
@@ -68,8 +74,14 @@ extern "C" int ymi_profile_end(double* ms_by_family, double* flop_by_family, int
         ms_by_family[r.family] += ms;
         flop_by_family[r.family] += r.flop;
         launches_by_family[r.family] += 1;
+        if (bytes_by_family) bytes_by_family[r.family] += r.bytes;
+        if (bound_ms_by_family) bound_ms_by_family[r.family] += r.bound_ms;
     }
     g_recs.clear();
     g_next = 0;
     return YMI_OK;
+}
+
+extern "C" int ymi_profile_end(double* ms_by_family, double* flop_by_family, int64_t* launches_by_family) {
+    return ymi_profile_end_ex(ms_by_family, flop_by_family, launches_by_family, nullptr, nullptr);
 }

@@ -234,10 +234,8 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
             k1[r] = sum_dz[c] * inv_count;
             k2[r] = sum_dzx[c] * inv_count;
         }
-        for (int64_t p = (int64_t)blockIdx.x * rows + threadIdx.x / groups; p < P; p += (int64_t)gridDim.x * rows) {
-            float d[4], x[4], o[4];
-            Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
-            Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+        auto one = [&](const float (&d)[4], const float (&x)[4], int64_t p) {
+            float o[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float xh = x[r] * p0[r] + p1[r];
@@ -245,6 +243,25 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
                 o[r] = ga[r] * p0[r] * (dz - k1[r] - xh * k2[r]);
             }
             Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
+        };
+        const int64_t step = (int64_t)gridDim.x * rows;
+        int64_t p = (int64_t)blockIdx.x * rows + threadIdx.x / groups;
+        // 4 pixels per trip: 8 independent loads in flight per lane before the first use
+        for (; p + 3 * step < P; p += 4 * step) {
+            float d[4][4], x[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                Pack<T, 4>::load(dp + (p + u * step) * dout.ld + g * 4, d[u]);
+                Pack<T, 4>::load(rp + (p + u * step) * raw.ld + g * 4, x[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) one(d[u], x[u], p + u * step);
+        }
+        for (; p < P; p += step) {
+            float d[4], x[4];
+            Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
+            Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+            one(d, x, p);
         }
     } else {
         const int64_t total = P * groups;
@@ -292,7 +309,7 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     const bool fixed = groups <= 256 && 256 % groups == 0;
     const int64_t total = P * groups;
     int64_t gb = fixed ? (P + 256 / groups - 1) / (256 / groups) : (total + 255) / 256;
-    if (gb > 4096) gb = 4096;
+    if (gb > 2048) gb = 2048;
     RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
     const float ic = 1.0f / (float)P;
 #define YMI_BWD_APPLY(T, F) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, F>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, ic, act)

@@ -16,7 +16,7 @@
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream);
 bool ymi_prof_enabled();
-int ymi_prof_start(hipStream_t stream, int family, double flop);
+int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, double peak_tflops);
 void ymi_prof_stop(hipStream_t stream, int idx);
 
 struct WgradArgs {
@@ -311,7 +311,11 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     dim3 grid((unsigned)((ng + WG_BN - 1) / WG_BN), (unsigned)((dy->c + WG_BM - 1) / WG_BM), (unsigned)p.splits);
     hipStream_t s = (hipStream_t)stream;
     int prof = -1;
-    if (ymi_prof_enabled()) prof = ymi_prof_start(s, 1, 2.0 * (double)mpix * (double)dy->c * (double)ng);
+    if (ymi_prof_enabled()) {
+        const double es = (double)ymi_esize(x->dtype);
+        const double bytes = ((double)ymi_pixels(x) * x->c + (double)mpix * dy->c) * es + (double)dy->c * ng * 4.0;
+        prof = ymi_prof_start(s, 1, 2.0 * (double)mpix * (double)dy->c * (double)ng, bytes, x->dtype == YMI_BF16 ? 2500.0 : 157.3);
+    }
     if (x->dtype == YMI_BF16) {
         static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
         const size_t lds = (size_t)ns * (size_t)(WG_BK * (WG_BM + WG_BN) * 2);

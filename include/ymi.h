@@ -55,6 +55,10 @@ const char* ymi_last_error(void);
  * family 1: weight-gradient GEMM): elapsed ms, algorithmic FLOP (2*M*N*K of the launch), launch count. */
 int ymi_profile_begin(int64_t capacity);
 int ymi_profile_end(double* ms_by_family, double* flop_by_family, int64_t* launches_by_family);
+/* as ymi_profile_end, plus per family: the algorithmic HBM bytes (operands read once, result written once) and the sum
+ * over launches of each launch's own roofline time max(flop / MFMA peak of its dtype, bytes / 8 TB/s), in ms. */
+int ymi_profile_end_ex(double* ms_by_family, double* flop_by_family, int64_t* launches_by_family, double* bytes_by_family,
+                       double* bound_ms_by_family);
 
 /* ---------------------------------------------------------------- layout / data movement ---- */
 
