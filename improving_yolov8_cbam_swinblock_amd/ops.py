@@ -736,3 +736,66 @@ def window_partition(x, ws):
     out = torch.empty((n * hp * wp, c), dtype=x.dtype, device=x.device)
     check(L().ymi_window_partition(_byref(as_ymi(x)), ws, _byref(as_ymi(out)), stream_ptr()), "window_partition")
     return out
+
+
+# ---- v8 detection loss on the Detect maps (csrc/loss.hip) -------------------------------------------------------
+def detect_targets(batch_idx, cls, bboxes, batch_size, max_boxes, img_w, img_h, device):
+    """ragged label rows -> dense [B, max_boxes, 5] (class, xyxy pixels); reference loss.py:176-191 preprocess."""
+    n = int(batch_idx.numel())
+    out = torch.empty(batch_size, max_boxes, 5, dtype=torch.float32, device=device)
+    bi = batch_idx.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    cl = cls.to(device=device, dtype=torch.float32).reshape(-1).contiguous()
+    bb = bboxes.to(device=device, dtype=torch.float32).reshape(-1, 4).contiguous()
+    check(L().ymi_detect_targets(ptr(bi) if n else None, ptr(cl) if n else None, ptr(bb) if n else None, n, batch_size, max_boxes, float(img_w),
+                                 float(img_h), ptr(out), stream_ptr()), "detect_targets")
+    return out
+
+
+def _map_array(maps):
+    return (_lib.YmiTensor * len(maps))(*[as_ymi(t) for t in maps])
+
+
+class _DetectLoss(torch.autograd.Function):
+    """(box maps, class maps) -> [3] = (box, cls, dfl) loss sums / max(sum of target scores, 1)."""
+
+    @staticmethod
+    def forward(ctx, targets, strides, topk, alpha, beta, *maps):
+        nl = len(maps) // 2
+        box, cls = maps[:nl], maps[nl:]
+        dev = box[0].device
+        b = box[0].shape[0]
+        anchors = sum(int(t.shape[2] * t.shape[3]) for t in box)
+        g = int(targets.shape[1])
+        sb, wb = ctypes.c_size_t(0), ctypes.c_size_t(0)
+        check(L().ymi_detect_loss_sizes(b, anchors, g, _byref(sb), _byref(wb)), "detect_loss_sizes")
+        state = torch.empty(sb.value, dtype=torch.uint8, device=dev)
+        ws = workspace(wb.value, dev, "detloss")
+        loss = torch.empty(3, dtype=torch.float32, device=dev)
+        st = (ctypes.c_float * nl)(*[float(s) for s in strides])
+        check(
+            L().ymi_detect_loss_fwd(nl, _map_array(box), _map_array(cls), st, ptr(targets), g, int(topk), float(alpha), float(beta), ptr(loss),
+                                    ptr(state), state.numel(), ptr(ws), ws.numel(), stream_ptr()),
+            "detect_loss_fwd",
+        )
+        ctx.save_for_backward(state, *maps)
+        ctx.strides = st
+        return loss
+
+    @staticmethod
+    def backward(ctx, gl):
+        state, *maps = ctx.saved_tensors
+        nl = len(maps) // 2
+        box, cls = maps[:nl], maps[nl:]
+        gl = gl.to(torch.float32).contiguous()
+        dbox = [torch.empty_like(t) for t in box]
+        dcls = [torch.empty_like(t) for t in cls]
+        check(
+            L().ymi_detect_loss_bwd(nl, _map_array(box), _map_array(cls), ctx.strides, ptr(state), state.numel(), ptr(gl), _map_array(dbox),
+                                    _map_array(dcls), stream_ptr()),
+            "detect_loss_bwd",
+        )
+        return (None, None, None, None, None, *dbox, *dcls)
+
+
+def detect_loss(box_maps, cls_maps, strides, targets, topk=10, alpha=0.5, beta=6.0):
+    return _DetectLoss.apply(targets, tuple(strides), topk, alpha, beta, *box_maps, *cls_maps)

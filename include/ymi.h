@@ -210,6 +210,28 @@ int ymi_colsum(const ymi_tensor* x, float* out /*[c]*/, void* workspace, size_t 
 /* dx = dy * gelu'(pre) (exact erf GELU, swin_block.py:33). */
 int ymi_gelu_bwd(const ymi_tensor* pre, const ymi_tensor* dy, const ymi_tensor* dx, void* stream);
 
+/* ---- v8 detection loss on the per-level Detect maps ----------------------------------------------------------
+ * Replaces v8DetectionLoss.__call__ (utils/loss.py:201-255) with its helpers: preprocess (loss.py:176-191),
+ * bbox_decode (loss.py:193-199), TaskAlignedAssigner.forward (utils/tal.py:45-104), BboxLoss / DFLoss
+ * (loss.py:65-120) and bbox_iou(CIoU=True) (utils/metrics.py:74-134).  box_maps[l] is the NHWC map
+ * [B,H_l,W_l,64] of Detect.cv2[l] (reg_max 16), cls_maps[l] the map [B,H_l,W_l,nc] of Detect.cv3[l]; anchors are
+ * ordered level by level, row-major, as the reference's concat.  All arithmetic is f32; maps may be f32 or bf16. */
+
+/* ragged label rows (image index, class, xywh normalised) -> dense out[batch, max_boxes, 5] = (class, xyxy in pixels);
+ * rows keep their order inside an image, unused slots are zero, rows beyond max_boxes of an image are dropped. */
+int ymi_detect_targets(const float* batch_idx, const float* cls, const float* bboxes_xywhn, int64_t n, int64_t batch, int64_t max_boxes,
+                       float img_w, float img_h, float* out, void* stream);
+/* bytes of the state (kept from forward to backward) and of the scratch workspace */
+int ymi_detect_loss_sizes(int64_t batch, int64_t anchors, int64_t max_boxes, size_t* state_bytes, size_t* workspace_bytes);
+/* loss_out[3] = (box, cls, dfl) sums divided by max(sum of target scores, 1), before the hyper-parameter gains.
+ * strides: host array [nl]; targets: device [batch, max_boxes, 5] as written by ymi_detect_targets. */
+int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const float* targets,
+                        int64_t max_boxes, int32_t topk, float alpha, float beta, float* loss_out, void* state, size_t state_bytes,
+                        void* workspace, size_t workspace_bytes, void* stream);
+/* gradients of sum_k grad_loss[k] * loss_out[k] with respect to the maps (grad_loss: device [3]) */
+int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const void* state,
+                        size_t state_bytes, const float* grad_loss, const ymi_tensor* dbox_maps, const ymi_tensor* dcls_maps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

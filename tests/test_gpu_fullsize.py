@@ -216,3 +216,32 @@ def test_config5_yolov8m_swin384_1280_runs_fwd_bwd():
     assert torch.isfinite(items).all()
     gn = [p.grad.float().norm() for p in model.parameters() if p.grad is not None]
     assert len(gn) > 100 and all(torch.isfinite(g) for g in gn)
+
+
+def test_hip_loss_fullsize_anchors_vs_oracle():
+    """8400 anchors per image (640x640), bf16 maps as in training, 6 images with 0..12 labels: HIP loss and its
+    gradients against the CPU oracle evaluated on the same (bf16-rounded) values."""
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+    from oracle.loss import v8DetectionLoss as OracleLoss
+    from oracle.tasks import DetectionModel as OracleModel
+
+    torch.manual_seed(0)
+    crit = DetectionModel("yolov8n-cbam.yaml", ch=3, nc=1).to(dev()).init_criterion()
+    ocrit = OracleLoss(OracleModel("yolov8n-cbam.yaml", ch=3, nc=1))
+    g = torch.Generator().manual_seed(5)
+    B = 6
+    preds = [(torch.randn(B, 65, s, s, generator=g) * 2).bfloat16() for s in (80, 40, 20)]
+    counts = [0, 1, 3, 12, 5, 2]
+    bi = torch.cat([torch.full((c,), float(i)) for i, c in enumerate(counts)])
+    n = int(bi.numel())
+    boxes = torch.cat((torch.rand(n, 2, generator=g) * 0.7 + 0.15, torch.rand(n, 2, generator=g) * 0.5 + 0.03), 1)
+    batch = {"batch_idx": bi, "cls": torch.zeros(n, 1), "bboxes": boxes}
+    pg = [p.clone().to(dev()).requires_grad_(True) for p in preds]
+    po = [p.float().requires_grad_(True) for p in preds]
+    a, _ = crit(pg, {k: v.to(dev()) for k, v in batch.items()})
+    b, _ = ocrit(po, batch)
+    torch.testing.assert_close(a.cpu(), b, rtol=5e-4, atol=1e-5)
+    a.sum().backward()
+    b.sum().backward()
+    for x, y in zip(pg, po):
+        assert rel(x.grad.detach(), y.grad) < 5e-3

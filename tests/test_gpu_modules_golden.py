@@ -270,3 +270,65 @@ def test_loss_matches_reference_on_fixed_predictions():
     loss.sum().backward()
     for i, p in enumerate(preds):
         assert torch.allclose(p.grad.cpu(), t(d[f"g.pred{i}"]), rtol=1e-3, atol=1e-5)
+
+
+def _oracle_crit(nc):
+    from oracle.loss import v8DetectionLoss as OracleLoss
+    from oracle.tasks import DetectionModel as OracleModel
+
+    cfg = json.loads((GOLDEN / "e2e_tiny_seed7_yaml.json").read_text())
+    return OracleLoss(OracleModel(cfg, ch=3, nc=nc))
+
+
+def _product_crit(nc):
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+
+    cfg = json.loads((GOLDEN / "e2e_tiny_seed7_yaml.json").read_text())
+    return DetectionModel(cfg, ch=3, nc=nc).to(dev()).init_criterion()
+
+
+@pytest.mark.parametrize("nc", [1, 5], ids=["nc1", "nc5"])
+@pytest.mark.parametrize("nb", [0, 1, 7, 40], ids=["empty", "one", "seven", "crowded"])
+def test_hip_loss_vs_oracle_random_batches(nb, nc):
+    """HIP loss (csrc/loss.hip) against the CPU oracle on random predictions: empty batch, images without labels,
+    several gts claiming one anchor; losses and gradients with respect to the prediction maps (f32)."""
+    crit, ocrit = _product_crit(nc), _oracle_crit(nc)
+    g = torch.Generator().manual_seed(3 + nb)
+    preds = [torch.randn(3, 64 + nc, s, s, generator=g) for s in (8, 4, 2)]
+    bi = torch.randint(0, 3, (nb,), generator=g).float()
+    boxes = torch.cat((torch.rand(nb, 2, generator=g) * 0.6 + 0.2, torch.rand(nb, 2, generator=g) * 0.4 + 0.05), 1)
+    cls = torch.randint(0, nc, (nb, 1), generator=g).float()
+    batch = {"batch_idx": bi, "cls": cls, "bboxes": boxes}
+    pg = [p.clone().to(dev()).requires_grad_(True) for p in preds]
+    po = [p.clone().requires_grad_(True) for p in preds]
+    a, ia = crit(pg, {k: v.to(dev()) for k, v in batch.items()})
+    b, ib = ocrit(po, batch)
+    torch.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5)
+    torch.testing.assert_close(ia.cpu(), ib, rtol=2e-4, atol=2e-5)
+    a.sum().backward()
+    b.sum().backward()
+    for x, y in zip(pg, po):
+        torch.testing.assert_close(x.grad.cpu(), y.grad, rtol=2e-3, atol=2e-5)
+
+
+def test_hip_loss_bf16_maps_and_max_boxes_hint():
+    """bf16 maps (the training dtype): same loss as on the f32 copy of the same bf16 values; a max_boxes hint larger
+    than needed changes nothing (the extra slots are padding rows)."""
+    crit, ocrit = _product_crit(1), _oracle_crit(1)
+    g = torch.Generator().manual_seed(11)
+    preds = [torch.randn(2, 65, s, s, generator=g).bfloat16() for s in (8, 4, 2)]
+    bi = torch.tensor([0.0, 0.0, 1.0, 1.0, 1.0])
+    boxes = torch.cat((torch.rand(5, 2, generator=g) * 0.6 + 0.2, torch.rand(5, 2, generator=g) * 0.4 + 0.05), 1)
+    batch = {"batch_idx": bi, "cls": torch.zeros(5, 1), "bboxes": boxes}
+    dbatch = {k: v.to(dev()) for k, v in batch.items()}
+    pg = [p.clone().to(dev()).requires_grad_(True) for p in preds]
+    po = [p.float().requires_grad_(True) for p in preds]
+    a, _ = crit(pg, dict(dbatch, max_boxes=9))
+    b, _ = ocrit(po, batch)
+    torch.testing.assert_close(a.cpu(), b, rtol=2e-4, atol=2e-5)
+    a.sum().backward()
+    b.sum().backward()
+    for x, y in zip(pg, po):  # gradients are rounded to bf16 on store
+        close_l2(x.grad, y.grad, 5e-3, "bf16 loss gradient")
+    a2, _ = crit([p.clone().to(dev()) for p in preds], dbatch)
+    torch.testing.assert_close(a2, a.detach(), rtol=1e-6, atol=1e-7)
