@@ -157,10 +157,10 @@ extern "C" int ymi_sppf_pool3_fwd(const ymi_tensor* y0, int64_t k, const ymi_ten
     const int cs = y0->dtype == YMI_BF16 ? 32 : 16;
     dim3 grid(((a.H + a.TH - 1) / a.TH) * ((a.W + a.TW - 1) / a.TW), (a.C + cs - 1) / cs, a.N);
     if (y0->dtype == YMI_BF16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(sppf_pool3_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(sppf_pool3_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
     }
     YMI_CHECK_LAUNCH("sppf_pool3_fwd");
@@ -175,10 +175,15 @@ struct PoolBwdArgs {
 };
 
 // one stage: gin[s] += sum_{p in window(s)} [argmax(x, window(p)) == s] gout[p]
-template <typename T>
+// NCH = 16-byte channel chunks per pixel owned by one workgroup (4: a 64-byte slab, coalesced for large maps;
+// 1: four times as many workgroups, for the small SPPF maps where the launch would not fill the chip otherwise).
+// The arg-max is separable: first the row maximum (and its column code) over the k columns, then the first row
+// whose row maximum is the window maximum: 2k LDS reads per window instead of k*k, and the same element as a
+// row-major scan with "strictly greater wins" (PyTorch's tie rule).
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
     constexpr int CN = Chunk<T>::N;
-    constexpr int CS = SlabTraits<T>::CS;
+    constexpr int CS = CN * NCH;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int r = a.k / 2, k = a.k;
     const int tiles_w = (a.W + a.TW - 1) / a.TW;
@@ -189,14 +194,16 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
     const int xh0 = max(th0 - 2 * r, 0), xh1 = min(th1 + 2 * r, a.H), xw0 = max(tw0 - 2 * r, 0), xw1 = min(tw1 + 2 * r, a.W);
     const int gh0 = max(th0 - r, 0), gh1 = min(th1 + r, a.H), gw0 = max(tw0 - r, 0), gw1 = min(tw1 + r, a.W);
     const int XH = xh1 - xh0, XW = xw1 - xw0, GH = gh1 - gh0, GW = gw1 - gw0;
-    char* X = smem;                                   // [XH][XW][64 B]
-    char* G = X + (size_t)XH * XW * 64;               // [GH][GW][64 B]
-    unsigned char* IDX = reinterpret_cast<unsigned char*>(G + (size_t)GH * GW * 64);  // [GH][GW][CS]
+    char* X = smem;                                          // [XH][XW][NCH * 16 B]
+    char* G = X + (size_t)XH * XW * NCH * 16;                // [GH][GW][NCH * 16 B]
+    char* RM = G + (size_t)GH * GW * NCH * 16;               // [XH][GW][NCH * 16 B] row maxima
+    unsigned char* IDX = reinterpret_cast<unsigned char*>(RM + (size_t)XH * GW * NCH * 16);  // [GH][GW][CS]
+    unsigned char* RC = IDX + (size_t)GH * GW * CS;          // [XH][GW][CS] column code of the row maximum
 
     const T* xs = reinterpret_cast<const T*>(a.x.p);
     const T* gs = reinterpret_cast<const T*>(a.gout.p);
-    for (int i = threadIdx.x; i < XH * XW * 4; i += 256) {
-        const int ch = i & 3, px = i >> 2;
+    for (int i = threadIdx.x; i < XH * XW * NCH; i += 256) {
+        const int ch = i % NCH, px = i / NCH;
         const int h = xh0 + px / XW, w = xw0 + px % XW;
         float v[CN];
         if (c0 + ch * CN < a.C) Chunk<T>::load(xs + (((int64_t)n * a.H + h) * a.W + w) * a.x.ld + c0 + ch * CN, v);
@@ -205,8 +212,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
             for (int e = 0; e < CN; ++e) v[e] = NEG_INF;
         Chunk<T>::store(X + (size_t)i * 16, v);
     }
-    for (int i = threadIdx.x; i < GH * GW * 4; i += 256) {
-        const int ch = i & 3, px = i >> 2;
+    for (int i = threadIdx.x; i < GH * GW * NCH; i += 256) {
+        const int ch = i % NCH, px = i / NCH;
         const int h = gh0 + px / GW, w = gw0 + px % GW;
         float v[CN];
         if (c0 + ch * CN < a.C) Chunk<T>::load(gs + (((int64_t)n * a.H + h) * a.W + w) * a.gout.ld + c0 + ch * CN, v);
@@ -216,10 +223,35 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
         Chunk<T>::store(G + (size_t)i * 16, v);
     }
     __syncthreads();
-    // arg-max code (dy*k + dx) of every window centred in the G region
-    for (int i = threadIdx.x; i < GH * GW * 4; i += 256) {
-        const int ch = i & 3, px = i >> 2;
-        const int h = gh0 + px / GW, w = gw0 + px % GW;
+    // row pass: for every staged row and every G column, the maximum over the k columns and its column code
+    for (int i = threadIdx.x; i < XH * GW * NCH; i += 256) {
+        const int ch = i % NCH, px = i / NCH;
+        const int hh = px / GW, w = gw0 + px % GW;
+        float best[CN];
+        int code[CN];
+#pragma unroll
+        for (int e = 0; e < CN; ++e) { best[e] = NEG_INF; code[e] = -1; }
+        for (int dx = 0; dx < k; ++dx) {
+            const int ww = w + dx - r;
+            if (ww < 0 || ww >= a.W) continue;
+            float v[CN];
+            Chunk<T>::load(X + ((size_t)(hh * XW + (ww - xw0)) * NCH + ch) * 16, v);
+#pragma unroll
+            for (int e = 0; e < CN; ++e)
+                if (code[e] < 0 || v[e] > best[e]) {  // first in-image element initialises; then strictly greater wins
+                    best[e] = v[e];
+                    code[e] = dx;
+                }
+        }
+        Chunk<T>::store(RM + (size_t)i * 16, best);
+#pragma unroll
+        for (int e = 0; e < CN; ++e) RC[(size_t)px * CS + ch * CN + e] = (unsigned char)code[e];
+    }
+    __syncthreads();
+    // column pass: arg-max code (dy*k + dx) of every window centred in the G region
+    for (int i = threadIdx.x; i < GH * GW * NCH; i += 256) {
+        const int ch = i % NCH, px = i / NCH;
+        const int h = gh0 + px / GW, wl = px % GW;
         float best[CN];
         int code[CN];
 #pragma unroll
@@ -227,18 +259,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
         for (int dy = 0; dy < k; ++dy) {
             const int hh = h + dy - r;
             if (hh < 0 || hh >= a.H) continue;
-            for (int dx = 0; dx < k; ++dx) {
-                const int ww = w + dx - r;
-                if (ww < 0 || ww >= a.W) continue;
-                float v[CN];
-                Chunk<T>::load(X + ((size_t)((hh - xh0) * XW + (ww - xw0)) * 4 + ch) * 16, v);
+            const size_t rp = (size_t)(hh - xh0) * GW + wl;
+            float v[CN];
+            Chunk<T>::load(RM + (rp * NCH + ch) * 16, v);
 #pragma unroll
-                for (int e = 0; e < CN; ++e)
-                    if (code[e] < 0 || v[e] > best[e]) {  // first in-image element initialises; then strictly greater wins
-                        best[e] = v[e];
-                        code[e] = dy * k + dx;
-                    }
-            }
+            for (int e = 0; e < CN; ++e)
+                if (code[e] < 0 || v[e] > best[e]) {
+                    best[e] = v[e];
+                    code[e] = dy * k + RC[rp * CS + ch * CN + e];
+                }
         }
 #pragma unroll
         for (int e = 0; e < CN; ++e) IDX[(size_t)px * CS + ch * CN + e] = (unsigned char)code[e];
@@ -246,8 +275,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
     __syncthreads();
     T* gi = reinterpret_cast<T*>(a.gin.p);
     const int TH = th1 - th0, TW = tw1 - tw0;
-    for (int i = threadIdx.x; i < TH * TW * 4; i += 256) {
-        const int ch = i & 3, px = i >> 2;
+    for (int i = threadIdx.x; i < TH * TW * NCH; i += 256) {
+        const int ch = i % NCH, px = i / NCH;
         const int h = th0 + px / TW, w = tw0 + px % TW;
         if (c0 + ch * CN >= a.C) continue;
         float acc[CN];
@@ -262,7 +291,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
                 const int want = (r - ay) * k + (r - ax);
                 const size_t gp = (size_t)(ph - gh0) * GW + (pw - gw0);
                 float g[CN];
-                Chunk<T>::load(G + (gp * 4 + ch) * 16, g);
+                Chunk<T>::load(G + (gp * NCH + ch) * 16, g);
 #pragma unroll
                 for (int e = 0; e < CN; ++e)
                     if (IDX[gp * CS + ch * CN + e] == want) acc[e] += g[e];
@@ -272,17 +301,25 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
     }
 }
 
+template <typename T, int NCH>
+static void launch_pool_bwd_t(const PoolBwdArgs& a, dim3 grid, size_t lds, hipStream_t stream) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_bwd_kernel<T, NCH>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL((maxpool_bwd_kernel<T, NCH>), grid, dim3(256), lds, stream, a);
+}
+
 static int launch_pool_bwd(const ymi_tensor* x, int k, const ymi_tensor* gout, const ymi_tensor* gin, hipStream_t stream) {
     PoolBwdArgs a{};
     a.x = PV{x->data, x->ld}; a.gout = PV{gout->data, gout->ld}; a.gin = PV{gin->data, gin->ld};
     a.N = (int)x->n; a.H = (int)x->h; a.W = (int)x->w; a.C = (int)x->c; a.k = k;
     const int r = k / 2;
-    const int cs = x->dtype == YMI_BF16 ? 32 : 16;
+    const int cn = x->dtype == YMI_BF16 ? 8 : 4;
+    const int nch = (a.H * a.W <= 1024) ? 1 : 4;  // small maps: one chunk per workgroup so the grid fills the chip
+    const int cs = cn * nch;
     int th = a.H, tw = a.W;
     auto bytes = [&](int t_h, int t_w) {
         const int XH = (t_h + 4 * r < a.H) ? t_h + 4 * r : a.H, XW = (t_w + 4 * r < a.W) ? t_w + 4 * r : a.W;
         const int GH = (t_h + 2 * r < a.H) ? t_h + 2 * r : a.H, GW = (t_w + 2 * r < a.W) ? t_w + 2 * r : a.W;
-        return (size_t)XH * XW * 64 + (size_t)GH * GW * (64 + cs);
+        return (size_t)XH * XW * nch * 16 + (size_t)GH * GW * (nch * 16 + cs) + (size_t)XH * GW * (nch * 16 + cs);
     };
     while (bytes(th, tw) > 150 * 1024) {
         if (th >= tw && th > 8) th = (th + 1) / 2;
@@ -296,11 +333,11 @@ static int launch_pool_bwd(const ymi_tensor* x, int k, const ymi_tensor* gout, c
     const size_t lds = bytes(th, tw);
     dim3 grid(((a.H + th - 1) / th) * ((a.W + tw - 1) / tw), (a.C + cs - 1) / cs, a.N);
     if (x->dtype == YMI_BF16) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, grid, dim3(256), lds, stream, a);
+        if (nch == 1) launch_pool_bwd_t<bf16_t, 1>(a, grid, lds, stream);
+        else launch_pool_bwd_t<bf16_t, 4>(a, grid, lds, stream);
     } else {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(maxpool_bwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, grid, dim3(256), lds, stream, a);
+        if (nch == 1) launch_pool_bwd_t<float, 1>(a, grid, lds, stream);
+        else launch_pool_bwd_t<float, 4>(a, grid, lds, stream);
     }
     YMI_CHECK_LAUNCH("sppf_pool3_bwd");
     return YMI_OK;
