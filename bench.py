@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--model", default="yolov8s.yaml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
-    ap.add_argument("--graph", type=int, default=-1, help="1: replay the step as a HIP graph, 0: eager, -1: graph when --gpus 1")
+    ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a HIP graph (several ranks: forward+backward graph, RCCL mean + update eager), 0: eager")
     args = ap.parse_args()
 
     from improving_yolov8_cbam_swinblock_amd import _lib
@@ -111,7 +111,7 @@ def main():
     torch.manual_seed(0)
     model = DetectionModel(args.model, ch=3, nc=1).to(dev)
     ddp.broadcast_parameters(model)
-    use_graph = (world == 1) if args.graph < 0 else bool(args.graph)
+    use_graph = bool(args.graph)
     step = TrainStep(model, world_size=world, graph=use_graph)
     batch = synthetic_batch(args.batch, args.imgsz, dev, ddp.shard_seed(1, rank))
 

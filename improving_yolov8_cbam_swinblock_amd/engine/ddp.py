@@ -3,10 +3,11 @@
 One process per GPU; `torch.distributed` backend "nccl" is RCCL on ROCm (gloo on CPU for tests).  The
 reference wraps the model in DistributedDataParallel; here the only exchange step of the path - the
 gradient mean over ranks - is done explicitly: parameters are grouped into a few large flat buckets
-(xGMI is point-to-point, 7 links per GPU: few large messages beat many small ones), each bucket's
-all-reduce is launched asynchronously from a post-accumulate-grad hook as soon as its last gradient
-is ready, so the collectives overlap the rest of backward, and `finish()` waits and scatters the
-averaged values back.  BatchNorm statistics stay per-rank (the reference has no SyncBatchNorm).
+(xGMI is point-to-point, 7 links per GPU: few large messages beat many small ones); a bucket is packed
+with one multi-tensor copy, all-reduced asynchronously (from a post-accumulate-grad hook as soon as its
+last gradient is ready when backward runs eagerly, right after the replay when backward is a HIP graph),
+and `finish()` waits, divides the flat buffer once and points `.grad` at its slices (no copy back).
+BatchNorm statistics stay per-rank (the reference has no SyncBatchNorm).
 """
 import os
 
@@ -42,10 +43,12 @@ def broadcast_parameters(module, src=0):
 
 
 class GradientBuckets:
-    """bucketed, backward-overlapped gradient mean.  Usage: gb = GradientBuckets(model, world); ...
-    loss.backward(); gb.finish()."""
+    """bucketed gradient mean.  overlap=True: each bucket's all-reduce starts from a post-accumulate-grad hook as
+    soon as its last gradient is ready (eager backward); overlap=False: `finish()` reduces everything after backward
+    (used when backward is a replayed HIP graph, which cannot call into RCCL).
+    Usage: gb = GradientBuckets(model, world); ... loss.backward(); gb.finish()."""
 
-    def __init__(self, module, world_size, bucket_bytes=32 << 20, comm_dtype=None):
+    def __init__(self, module, world_size, bucket_bytes=32 << 20, comm_dtype=None, overlap=True):
         self.world = world_size
         self.comm_dtype = comm_dtype
         params = [p for p in module.parameters() if p.requires_grad]
@@ -62,23 +65,28 @@ class GradientBuckets:
             self.buckets.append(cur)
         self._where = {}
         self._flat = []
+        self._views = []  # per bucket: slices of the flat buffer shaped like the parameters
         for bi, b in enumerate(self.buckets):
             for p in b:
                 self._where[p] = bi
             n = sum(p.numel() for p in b)
-            self._flat.append(torch.zeros(n, dtype=comm_dtype or b[0].dtype, device=b[0].device))
+            flat = torch.zeros(n, dtype=comm_dtype or b[0].dtype, device=b[0].device)
+            views, off = [], 0
+            for p in b:
+                views.append(flat[off : off + p.numel()].view_as(p))
+                off += p.numel()
+            self._flat.append(flat)
+            self._views.append(views)
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params] if world_size > 1 else []
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params] if (world_size > 1 and overlap) else []
 
-    def _launch(self, bi):
-        flat = self._flat[bi]
-        off = 0
-        for p in self.buckets[bi]:
-            n = p.numel()
-            flat[off : off + n].copy_(p.grad.reshape(-1))
-            off += n
-        self._work[bi] = dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=True)
+    def _launch(self, bi, grads=None):
+        """pack the bucket's gradients into its flat buffer (one multi-tensor copy) and start the all-reduce."""
+        if grads is None:
+            grads = [p.grad for p in self.buckets[bi]]
+        torch._foreach_copy_(self._views[bi], grads)
+        self._work[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
 
     def _on_grad(self, p):
         bi = self._where[p]
@@ -86,23 +94,26 @@ class GradientBuckets:
         if self._pending[bi] == 0:
             self._launch(bi)
 
-    def finish(self):
-        """wait for every bucket, write grad = sum / world back into .grad, re-arm for the next step."""
+    def finish(self, grads_of=None):
+        """wait for every bucket and leave grad = sum / world in .grad (as views of the flat buffers: no copy back);
+        re-arm for the next step.  grads_of: optional {param: gradient tensor} to reduce instead of .grad."""
         if self.world == 1:
             return
         for bi, b in enumerate(self.buckets):
-            if self._work[bi] is None:  # parameters without a gradient this step (unused): reduce what exists
-                for p in b:
-                    if p.grad is None:
-                        p.grad = torch.zeros_like(p)
-                self._launch(bi)
+            if self._work[bi] is None:  # no hook fired (overlap off, or parameters without a gradient this step)
+                if grads_of is not None:
+                    src = [grads_of[p] if p in grads_of else torch.zeros_like(p) for p in b]
+                else:
+                    for p in b:
+                        if p.grad is None:
+                            p.grad = torch.zeros_like(p)
+                    src = None
+                self._launch(bi, src)
+        for bi, b in enumerate(self.buckets):
             self._work[bi].wait()
-            flat = self._flat[bi]
-            off = 0
-            for p in b:
-                n = p.numel()
-                p.grad.copy_(flat[off : off + n].view_as(p.grad)).div_(self.world)
-                off += n
+            self._flat[bi].div_(self.world)
+            for p, v in zip(b, self._views[bi]):
+                p.grad = v if v.dtype == p.dtype else v.to(p.dtype)
             self._work[bi] = None
             self._pending[bi] = len(b)
 
@@ -111,11 +122,5 @@ def allreduce_mean_gradients(module, world_size, bucket_bytes=32 << 20):
     """non-overlapped form (tests, and callers that already ran backward)."""
     if world_size == 1:
         return
-    gb = GradientBuckets(module, 1, bucket_bytes)  # no hooks
-    gb.world = world_size
-    for bi, b in enumerate(gb.buckets):
-        for p in b:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        gb._launch(bi)
+    gb = GradientBuckets(module, world_size, bucket_bytes, overlap=False)
     gb.finish()

@@ -46,22 +46,27 @@ def synthetic_batch(batch, imgsz, device, seed, boxes_per_image=4):
 
 class TrainStep:
     """one optimisation step: forward under autocast, loss.sum() * world (reference trainer.py:386-388), backward
-    with bucketed RCCL mean, unscale-free clip (bf16 needs no GradScaler), optimizer step, zero_grad."""
+    with bucketed RCCL mean, unscale-free clip (bf16 needs no GradScaler), optimizer step, zero_grad.
+
+    graph=True replays the step as a HIP graph (every kernel of libyolo_mi355 only enqueues on the stream it is
+    given, so the capture is legal; needs static shapes: batch["max_boxes"] must be set):
+      * one rank: the whole step (forward, loss, backward, clip, update) is one graph;
+      * several ranks: forward + loss + backward are one graph; the RCCL gradient mean, the clip and the update run
+        eagerly after the replay (a dozen launches), because RCCL calls are not captured."""
 
     def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20, graph=False):
         self.model = model
         self.world = world_size
         self.dtype = dtype
         self.opt = build_optimizer(model, lr=lr)
-        self.buckets = GradientBuckets(model, world_size, bucket_bytes)
+        self.use_graph = bool(graph)
+        self.full_graph = self.use_graph and world_size == 1 and graph != "split"  # graph="split": the multi-rank form on one rank
+        self.buckets = GradientBuckets(model, world_size, bucket_bytes, overlap=not self.use_graph)
         self.params = [p for p in model.parameters() if p.requires_grad]
-        # graph=True: the whole step (forward, loss, backward, clip, update) is captured once into a HIP graph and
-        # replayed; every kernel of libyolo_mi355 only enqueues on the stream it is given, so the capture is legal.
-        # Needs static shapes: batch["max_boxes"] must be set.  Single-rank only (RCCL work stays eager).
-        self.use_graph = bool(graph) and world_size == 1
         self._graph = None
         self._static = None
         self._static_items = None
+        self._graph_grads = None
 
     def __call__(self, batch):
         if not self.use_graph:
@@ -80,22 +85,40 @@ class TrainStep:
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self._graph):
-                self._static_items = self.eager_step(self._static)
+                if self.full_graph:
+                    self._static_items = self.eager_step(self._static)
+                else:
+                    self._static_items = self._forward_backward(self._static)
+            if not self.full_graph:  # the gradients the replays rewrite in place
+                self._graph_grads = {p: p.grad for p in self.params if p.grad is not None}
         else:
             for k, v in batch.items():
                 if torch.is_tensor(v) and v is not self._static[k]:
                     self._static[k].copy_(v)
         self._graph.replay()
+        if not self.full_graph:
+            self._reduce_and_update(self._graph_grads)
+            self.opt.zero_grad(set_to_none=True)  # drops references only: the graph owns its gradient buffers
         return self._static_items
 
-    def eager_step(self, batch):
+    def _forward_backward(self, batch):
         self.model.train()
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             loss, items = self.model(batch)
             total = loss.sum() * self.world
         total.backward()
-        self.buckets.finish()
+        return items
+
+    def _reduce_and_update(self, grads_of=None):
+        if grads_of is not None and self.world == 1:  # (single-rank use of the split path: tests)
+            for p, g in grads_of.items():
+                p.grad = g
+        self.buckets.finish(grads_of)
         torch.nn.utils.clip_grad_norm_(self.params, max_norm=10.0)
         self.opt.step()
+
+    def eager_step(self, batch):
+        items = self._forward_backward(batch)
+        self._reduce_and_update()
         self.opt.zero_grad(set_to_none=True)
         return items

@@ -118,14 +118,15 @@ def test_hip_graph_step_matches_eager_and_is_isolated(bs, sz):
     from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
 
     losses = {}
-    for mode in ("eager", "graph"):
+    # "split": forward + loss + backward as a graph, gradient reduction / clip / update eager (the multi-rank form)
+    for mode in ("eager", "graph", "split"):
         torch.manual_seed(0)
         model = DetectionModel("yolov8s.yaml", ch=3, nc=1).to(dev())
-        step = TrainStep(model, world_size=1, lr=0.01, graph=(mode == "graph"))
+        step = TrainStep(model, world_size=1, lr=0.01, graph={"eager": False, "graph": True, "split": "split"}[mode])
         batch = synthetic_batch(bs, sz, dev(), 1)
         out = []
         for i in range(7):
-            if mode == "graph" and i >= 4:  # eager allocations between replays
+            if mode != "eager" and i >= 4:  # eager allocations between replays
                 junk = [torch.full((n,), 7.0, device=dev()) for n in (1, 3, 17, 1000, 100000, 5000000)]
                 junk.append(torch.randn(1000, 1000, device=dev()).sum())
                 torch.cuda.synchronize()
@@ -141,6 +142,7 @@ def test_hip_graph_step_matches_eager_and_is_isolated(bs, sz):
     assert float(losses["eager"][-1].sum()) < float(losses["eager"][0].sum())
     # eager steps 3.. and graph steps 0.. see the same weights (identical kernels, deterministic): equal to float noise
     torch.testing.assert_close(losses["graph"][:4], losses["eager"][3:7], rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(losses["split"][:4], losses["eager"][3:7], rtol=2e-2, atol=2e-2)
 
 
 def _copy_state(dst, src):
@@ -245,3 +247,56 @@ def test_hip_loss_fullsize_anchors_vs_oracle():
     b.sum().backward()
     for x, y in zip(pg, po):
         assert rel(x.grad.detach(), y.grad) < 5e-3
+
+
+def _ddp_worker(rank, world, port, graph, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    # both ranks share the box's single GPU, which RCCL refuses: gloo moves the CUDA buckets instead; everything
+    # above the collective (bucket packing, graph replay + eager tail, update) is the code the multi-GPU run uses
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from improving_yolov8_cbam_swinblock_amd.engine import ddp
+    from improving_yolov8_cbam_swinblock_amd.engine.trainer import TrainStep, synthetic_batch
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+
+    d = torch.device("cuda", 0)
+    torch.manual_seed(100 + rank)  # different initial weights: the broadcast must equalise them
+    model = DetectionModel("yolov8n-cbam.yaml", ch=3, nc=1).to(d)
+    ddp.broadcast_parameters(model)
+    step = TrainStep(model, world_size=world, graph=graph)
+    batch = synthetic_batch(2, 320, d, ddp.shard_seed(1, rank))
+    items = [step(batch).float().cpu() for _ in range(5)]
+    torch.cuda.synchronize()
+    flat = torch.cat([p.detach().float().reshape(-1).cpu() for p in model.parameters()])
+    q.put((rank, torch.stack(items).numpy(), flat.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", [False, True], ids=["eager_overlapped", "graph_plus_eager_tail"])
+def test_two_rank_training_keeps_replicas_identical(graph):
+    """2 ranks (gloo over CUDA tensors, one GPU): after 5 steps on different shards the replicas hold identical
+    parameters (gradient mean applied on both) and the losses differ per shard."""
+    import socket
+
+    import numpy as np
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, graph, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(120)
+    assert np.isfinite(res[0][1]).all() and np.isfinite(res[1][1]).all()
+    assert not np.allclose(res[0][1], res[1][1])  # different shards
+    np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)
