@@ -98,7 +98,10 @@ template <> struct Pack<bf16_t, 8> {
     }
 };
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// e^x as one v_exp_f32 (2^(x*log2 e)): ~1 ulp, results below 2^-126 flush to zero; no range-reduction code
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// 1 / (1 + e^-x) with v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of the IEEE division sequence
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
 __device__ __forceinline__ float silu_f(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float silu_grad_f(float x) {
     float s = sigmoidf_(x);
@@ -107,7 +110,7 @@ __device__ __forceinline__ float silu_grad_f(float x) {
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float c = 0.39894228040143267794f;  // 1/sqrt(2 pi)
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * c * __expf(-0.5f * x * x);
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * c * fast_exp(-0.5f * x * x);
 }
 template <int ACT> __device__ __forceinline__ float apply_act(float x) {
     if (ACT == YMI_ACT_SILU) return silu_f(x);
@@ -116,6 +119,11 @@ template <int ACT> __device__ __forceinline__ float apply_act(float x) {
 }
 __device__ __forceinline__ float apply_act_rt(float x, int act) {
     return act == YMI_ACT_SILU ? silu_f(x) : act == YMI_ACT_GELU ? gelu_f(x) : x;
+}
+template <int ACT> __device__ __forceinline__ float act_grad(float x) {
+    if (ACT == YMI_ACT_SILU) return silu_grad_f(x);
+    if (ACT == YMI_ACT_GELU) return gelu_grad_f(x);
+    return 1.0f;
 }
 __device__ __forceinline__ float act_grad_rt(float x, int act) {
     return act == YMI_ACT_SILU ? silu_grad_f(x) : act == YMI_ACT_GELU ? gelu_grad_f(x) : 1.0f;

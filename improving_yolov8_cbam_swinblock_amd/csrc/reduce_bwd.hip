@@ -13,9 +13,9 @@ struct RV {
 // FN: 0 colsum(a)            -> s0 = sum a
 //     1 bn-act backward      -> dz = a * act'(z), z = (b-mean)*inv*gamma+beta ; s0 = sum dz, s1 = sum dz*xhat
 //     2 layernorm param grads-> s0 = sum a (dbeta), s1 = sum a * (b - mean_row)*rstd_row (dgamma); mean/rstd per ROW
-template <typename T, int FN>
+template <typename T, int FN, int ACT>
 __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ mean, const float* __restrict__ inv, int act, float* __restrict__ part) {
+                                   const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part) {
     extern __shared__ float red[];  // [rows][TG][8]
     const int rows = 256 / TG;
     const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
@@ -44,7 +44,7 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float xh = (vb[r] - mu[r]) * iv[r];
-                    const float dz = va[r] * act_grad_rt(xh * g[r] + be[r], act);
+                    const float dz = va[r] * act_grad<ACT>(xh * g[r] + be[r]);
                     s0[r] += dz;
                     s1[r] += dz * xh;
                 }
@@ -167,10 +167,17 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
     const int blocks = reduce_blocks(P);
     const size_t lds = (size_t)256 * 8 * sizeof(float);
     RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
-    if (a->dtype == YMI_BF16)
-        hipLaunchKernelGGL((chan_reduce_kernel<bf16_t, FN>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
-    else
-        hipLaunchKernelGGL((chan_reduce_kernel<float, FN>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, act, part);
+#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, part)
+#define YMI_CR_T(T)                                                      \
+    do {                                                                 \
+        if (FN != 1 || act == YMI_ACT_NONE) YMI_CR(T, YMI_ACT_NONE);     \
+        else if (act == YMI_ACT_SILU) YMI_CR(T, YMI_ACT_SILU);           \
+        else YMI_CR(T, YMI_ACT_GELU);                                    \
+    } while (0)
+    if (a->dtype == YMI_BF16) YMI_CR_T(bf16_t);
+    else YMI_CR_T(float);
+#undef YMI_CR_T
+#undef YMI_CR
     YMI_CHECK_LAUNCH(what);
     *blocks_out = blocks;
     return YMI_OK;
@@ -212,11 +219,11 @@ int ymi_ln_param_grads(const ymi_tensor* dy, const ymi_tensor* x, const float* m
 // draw = gamma*inv*(dz - mean(dz) - xhat*mean(dz*xhat))
 // FIXED: the number of 4-channel groups divides 256, so a thread keeps one channel group and its
 // per-channel coefficients in registers for all of its pixels.
-template <typename T, bool FIXED>
+template <typename T, bool FIXED, int ACT>
 __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t P, int C, const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, const float* __restrict__ mean,
                                                                const float* __restrict__ inv, const float* __restrict__ sum_dz,
-                                                               const float* __restrict__ sum_dzx, float inv_count, int act) {
+                                                               const float* __restrict__ sum_dzx, float inv_count) {
     const int groups = C / 4;
     const T* dp = reinterpret_cast<const T*>(dout.p);
     const T* rp = reinterpret_cast<const T*>(raw.p);
@@ -239,7 +246,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float xh = x[r] * p0[r] + p1[r];
-                const float dz = d[r] * act_grad_rt(xh * ga[r] + be[r], act);
+                const float dz = d[r] * act_grad<ACT>(xh * ga[r] + be[r]);
                 o[r] = ga[r] * p0[r] * (dz - k1[r] - xh * k2[r]);
             }
             Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
@@ -276,7 +283,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
                 const int c = g * 4 + r;
                 const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
                 const float xh = (x[r] - mean[c]) * inv[c];
-                const float dz = d[r] * act_grad_rt(xh * ga + be, act);
+                const float dz = d[r] * act_grad<ACT>(xh * ga + be);
                 o[r] = ga * inv[c] * (dz - sum_dz[c] * inv_count - xh * sum_dzx[c] * inv_count);
             }
             Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
@@ -312,14 +319,21 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     if (gb > 2048) gb = 2048;
     RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
     const float ic = 1.0f / (float)P;
-#define YMI_BWD_APPLY(T, F) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, F>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, ic, act)
+#define YMI_BWD_APPLY(T, F, A) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, F, A>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, ic)
+#define YMI_BWD_APPLY_A(T, F)                                     \
+    do {                                                          \
+        if (act == YMI_ACT_SILU) YMI_BWD_APPLY(T, F, YMI_ACT_SILU); \
+        else if (act == YMI_ACT_GELU) YMI_BWD_APPLY(T, F, YMI_ACT_GELU); \
+        else YMI_BWD_APPLY(T, F, YMI_ACT_NONE);                   \
+    } while (0)
     if (dout->dtype == YMI_BF16) {
-        if (fixed) YMI_BWD_APPLY(bf16_t, true);
-        else YMI_BWD_APPLY(bf16_t, false);
+        if (fixed) YMI_BWD_APPLY_A(bf16_t, true);
+        else YMI_BWD_APPLY_A(bf16_t, false);
     } else {
-        if (fixed) YMI_BWD_APPLY(float, true);
-        else YMI_BWD_APPLY(float, false);
+        if (fixed) YMI_BWD_APPLY_A(float, true);
+        else YMI_BWD_APPLY_A(float, false);
     }
+#undef YMI_BWD_APPLY_A
 #undef YMI_BWD_APPLY
     YMI_CHECK_LAUNCH("bn_act_bwd(apply)");
     return YMI_OK;
