@@ -41,11 +41,29 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, int C, int64_
     }
 }
 
+// image path (C <= 8 into 8 bf16 channels): one thread per pixel reads the C planes (coalesced over pixels) and
+// writes ONE 16-byte chunk, so a wave stores 1 KiB contiguously
+__global__ __launch_bounds__(256) void nchw_to_nhwc8_bf16_kernel(const float* __restrict__ src, int C, uint32_t HW, uint32_t NP, TV d) {
+    bf16_t* dst = reinterpret_cast<bf16_t*>(d.p);
+    for (uint32_t p = blockIdx.x * 256u + threadIdx.x; p < NP; p += gridDim.x * 256u) {
+        const uint32_t n = p / HW, hw = p - n * HW;
+        float v[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) v[c] = c < C ? src[((uint64_t)n * C + c) * HW + hw] : 0.0f;
+        Pack<bf16_t, 8>::store(dst + (uint64_t)p * d.ld, v);
+    }
+}
+
 extern "C" int ymi_nchw_to_nhwc(const float* src, int64_t n, int64_t c, int64_t h, int64_t w, const ymi_tensor* dst, void* stream) {
     YMI_CHECK_ARG(src && ymi_tensor_ok(dst), "nchw_to_nhwc: bad tensor");
     YMI_CHECK_ARG(dst->n == n && dst->h == h && dst->w == w && dst->c >= c, "nchw_to_nhwc: shape");
     YMI_CHECK_ARG(vec4_ok(dst), "nchw_to_nhwc: destination must be 4-channel aligned");
     const int64_t np = n * h * w, total = np * (dst->c / 4);
+    if (dst->dtype == YMI_BF16 && dst->c == 8 && dst->ld % 8 == 0 && ((uintptr_t)dst->data & 15) == 0 && np < (1ll << 31)) {
+        hipLaunchKernelGGL(nchw_to_nhwc8_bf16_kernel, ew_grid(np), dim3(256), 0, (hipStream_t)stream, src, (int)c, (uint32_t)(h * w), (uint32_t)np, tv(dst));
+        YMI_CHECK_LAUNCH("nchw_to_nhwc");
+        return YMI_OK;
+    }
     if (dst->dtype == YMI_BF16)
         hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, ew_grid(total), dim3(256), 0, (hipStream_t)stream, src, (int)c, h * w, np, tv(dst));
     else
@@ -86,13 +104,19 @@ __global__ void move_kernel(TV s, TV d) {
     const int64_t total = (int64_t)d.n * d.h * d.w * groups;
     const TS* src = reinterpret_cast<const TS*>(s.p);
     TD* dst = reinterpret_cast<TD*>(d.p);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const int64_t p = i / groups;
-        const int w = (int)(p % d.w);
-        const int64_t t = p / d.w;
-        const int h = (int)(t % d.h);
-        const int n = (int)(t / d.h);
+    // 32-bit index arithmetic (launch_move checks total < 2^31): 64-bit division would dominate this kernel
+    const uint32_t total32 = (uint32_t)total, ugroups = (uint32_t)groups, uw = (uint32_t)d.w, uh = (uint32_t)d.h;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += gridDim.x * blockDim.x) {
+        const uint32_t pu = i / ugroups;
+        const int g = (int)(i - pu * ugroups);
+        const int64_t p = pu;
+        int w = 0, h = 0, n = 0;
+        if (MODE == 1 || MODE == 2) {
+            const uint32_t t = pu / uw;
+            w = (int)(pu - t * uw);
+            n = (int)(t / uh);
+            h = (int)(t - (uint32_t)n * uh);
+        }
         float v[G];
         auto ld = [&](int64_t sp, float (&o)[G]) {
             if constexpr (VEC) Pack<TS, 4>::load(src + sp * s.ld + g * 4, o);
@@ -125,6 +149,7 @@ template <int MODE>
 static int launch_move(const ymi_tensor* src, const ymi_tensor* dst, const char* what, hipStream_t stream) {
     const bool vec = vec4_ok(src) && vec4_ok(dst);
     const int64_t total = ymi_pixels(dst) * (vec ? dst->c / 4 : dst->c);
+    YMI_CHECK_ARG(total < (1ll << 31), "%s: tensor too large for 32-bit indexing", what);
     dim3 g = ew_grid(total), b(256);
 #define YMI_MV(TS, TD)                                                                              \
     do {                                                                                            \
@@ -363,9 +388,11 @@ __global__ void scale_shift_act_kernel(TV x, const float* __restrict__ scale, co
     const T* xp = reinterpret_cast<const T*>(x.p);
     const T* rp = reinterpret_cast<const T*>(res.p);
     T* op = reinterpret_cast<T*>(o.p);
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const int64_t p = i / groups;
+    const uint32_t total32 = (uint32_t)total, ugroups = (uint32_t)groups;  // host: total < 2^31
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total32; i += gridDim.x * blockDim.x) {
+        const uint32_t pu = i / ugroups;
+        const int g = (int)(i - pu * ugroups);
+        const int64_t p = pu;
         float v[G];
         if constexpr (VEC) Pack<T, 4>::load(xp + p * x.ld + g * 4, v);
         else v[0] = to_f32(xp[p * x.ld + g]);
@@ -448,6 +475,7 @@ extern "C" int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, co
     if (residual) YMI_CHECK_ARG(ymi_tensor_ok(residual) && ymi_same_shape(residual, out) && residual->dtype == out->dtype, "scale_shift_act: residual");
     const bool vec = vec4_ok(raw) && vec4_ok(out) && (!residual || vec4_ok(residual));
     const int64_t total = ymi_pixels(raw) * (vec ? raw->c / 4 : raw->c);
+    YMI_CHECK_ARG(total < (1ll << 31), "scale_shift_act: tensor too large for 32-bit indexing");
     TV r = residual ? tv(residual) : TV{nullptr, 0, 0, 0, 0, 0};
     dim3 g = ew_grid(total), b(256);
     hipStream_t s = (hipStream_t)stream;

@@ -20,45 +20,48 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
         else hi = mid;
     }
     const PackDesc d = descs[lo];
-    const int64_t base = ((int64_t)blockIdx.x - block_start[lo]) * 1024;
-    const int taps = d.kh * d.kw;
-    const int64_t nfwd = d.dst_fwd ? (int64_t)d.o * taps * d.ipad : 0;
-    const int64_t ndg = d.dst_dgrad ? (int64_t)d.i * taps * d.opad : 0;
+    // 32-bit index arithmetic throughout (the host checks every operand has < 2^31 elements): 64-bit integer
+    // division costs an order of magnitude more instructions and this kernel is nothing but index arithmetic
+    const uint32_t base = (uint32_t)((int)blockIdx.x - block_start[lo]) * 1024u;
+    const uint32_t taps = (uint32_t)(d.kh * d.kw);
+    const uint32_t nfwd = d.dst_fwd ? (uint32_t)d.o * taps * (uint32_t)d.ipad : 0u;
+    const uint32_t ndg = d.dst_dgrad ? (uint32_t)d.i * taps * (uint32_t)d.opad : 0u;
     const int pad = d.kh / 2;
+    const int smask = d.stride - 1;  // stride is 1 or 2: (v % stride == 0) <=> ((v & smask) == 0), without a division
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-        const int64_t idx = base + u * 256 + threadIdx.x;
+        const uint32_t idx = base + u * 256 + threadIdx.x;
         if (idx < nfwd) {  // dst[o][kh][kw][ip] <- src[o][i][kh][kw]
-            const int ip = (int)(idx % d.ipad);
-            int64_t t = idx / d.ipad;
-            const int tp = (int)(t % taps);
-            const int o = (int)(t / taps);
-            const float v = ip < d.i ? d.src[((int64_t)o * d.i + ip) * taps + tp] : 0.0f;
+            const uint32_t t = idx / (uint32_t)d.ipad;
+            const uint32_t ip = idx - t * (uint32_t)d.ipad;
+            const uint32_t o = t / taps;
+            const uint32_t tp = t - o * taps;
+            const float v = ip < (uint32_t)d.i ? d.src[(o * (uint32_t)d.i + ip) * taps + tp] : 0.0f;
             reinterpret_cast<T*>(d.dst_fwd)[idx] = from_f32<T>(v);
         }
         if (idx < ndg) {  // class blocks back to back: dst[ci][t_in_class][op] <- src[o][ci][kh_t][kw_t]
-            int64_t rem = idx;
+            uint32_t rem = idx;
             const int nclass = d.stride == 1 ? 1 : 4;
             for (int cls = 0; cls < nclass; ++cls) {
                 const int ph = d.stride == 1 ? 0 : cls >> 1, pw = d.stride == 1 ? 0 : cls & 1;
                 int nt = 0;
                 for (int a = 0; a < d.kh; ++a)
                     for (int b = 0; b < d.kw; ++b)
-                        if ((ph + pad - a) % d.stride == 0 && (pw + pad - b) % d.stride == 0) ++nt;
-                const int64_t sz = (int64_t)d.i * nt * d.opad;
+                        if (((ph + pad - a) & smask) == 0 && ((pw + pad - b) & smask) == 0) ++nt;
+                const uint32_t sz = (uint32_t)d.i * (uint32_t)nt * (uint32_t)d.opad;
                 if (rem < sz) {
-                    const int o = (int)(rem % d.opad);
-                    int64_t t = rem / d.opad;
-                    const int tq = (int)(t % nt);
-                    const int ci = (int)(t / nt);
+                    const uint32_t t = rem / (uint32_t)d.opad;
+                    const int o = (int)(rem - t * (uint32_t)d.opad);
+                    const uint32_t ci = t / (uint32_t)nt;
+                    const int tq = (int)(t - ci * (uint32_t)nt);
                     int seen = 0, ka = 0, kb = 0;
                     for (int a = 0; a < d.kh; ++a)
                         for (int b = 0; b < d.kw; ++b)
-                            if ((ph + pad - a) % d.stride == 0 && (pw + pad - b) % d.stride == 0) {
+                            if (((ph + pad - a) & smask) == 0 && ((pw + pad - b) & smask) == 0) {
                                 if (seen == tq) { ka = a; kb = b; }
                                 ++seen;
                             }
-                    const float v = o < d.o ? d.src[(((int64_t)o * d.i + ci) * d.kh + ka) * d.kw + kb] : 0.0f;
+                    const float v = o < d.o ? d.src[(((uint32_t)o * (uint32_t)d.i + ci) * (uint32_t)d.kh + (uint32_t)ka) * (uint32_t)d.kw + (uint32_t)kb] : 0.0f;
                     reinterpret_cast<T*>(d.dst_dgrad)[idx] = from_f32<T>(v);
                     break;
                 }

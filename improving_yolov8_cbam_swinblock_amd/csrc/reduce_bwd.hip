@@ -271,10 +271,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
             one(d, x, p);
         }
     } else {
-        const int64_t total = P * groups;
-        for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-            const int g = (int)(i % groups);
-            const int64_t p = i / groups;
+        const uint32_t total = (uint32_t)(P * groups), ugroups = (uint32_t)groups;  // host: P * groups < 2^31
+        for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+            const uint32_t pu = i / ugroups;
+            const int g = (int)(i - pu * ugroups);
+            const int64_t p = pu;
             float d[4], x[4], o[4];
             Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
             Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
@@ -315,6 +316,7 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     const int groups = C / 4;
     const bool fixed = groups <= 256 && 256 % groups == 0;
     const int64_t total = P * groups;
+    YMI_CHECK_ARG(total < (1ll << 31), "bn_act_bwd: tensor too large for 32-bit indexing");
     int64_t gb = fixed ? (P + 256 / groups - 1) / (256 / groups) : (total + 255) / 256;
     if (gb > 2048) gb = 2048;
     RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
@@ -343,13 +345,14 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
 template <typename T>
 __global__ void gelu_bwd_kernel(RV pre, RV dy, RV dx, int64_t P, int C) {
     const int groups = C / 4;
-    const int64_t total = P * groups;
+    const uint32_t total = (uint32_t)(P * groups), ugroups = (uint32_t)groups;  // host: P * groups < 2^31
     const T* pp = reinterpret_cast<const T*>(pre.p);
     const T* dp = reinterpret_cast<const T*>(dy.p);
     T* op = reinterpret_cast<T*>(const_cast<void*>(dx.p));
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const int64_t p = i / groups;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t pu = i / ugroups;
+        const int g = (int)(i - pu * ugroups);
+        const int64_t p = pu;
         float a[4], d[4];
         Pack<T, 4>::load(pp + p * pre.ld + g * 4, a);
         Pack<T, 4>::load(dp + p * dy.ld + g * 4, d);
@@ -363,6 +366,7 @@ extern "C" int ymi_gelu_bwd(const ymi_tensor* pre, const ymi_tensor* dy, const y
     YMI_CHECK_ARG(ymi_tensor_ok(pre) && ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && ymi_same_shape(pre, dy) && ymi_same_shape(pre, dx), "gelu_bwd: shapes");
     YMI_CHECK_ARG(pre->dtype == dy->dtype && dy->dtype == dx->dtype && pre->c % 4 == 0 && pre->ld % 4 == 0 && dy->ld % 4 == 0 && dx->ld % 4 == 0, "gelu_bwd: dtype/alignment");
     const int64_t P = ymi_pixels(pre), total = P * (pre->c / 4);
+    YMI_CHECK_ARG(total < (1ll << 31), "gelu_bwd: tensor too large for 32-bit indexing");
     int64_t gb = (total + 255) / 256;
     if (gb > 4096) gb = 4096;
     RV a{pre->data, pre->ld}, b{dy->data, dy->ld}, o{dx->data, dx->ld};

@@ -20,15 +20,15 @@ struct SV {
 };
 
 // token t (window order) -> pixel of the padded grid, -1 if outside the real image.  swin_block.py:8-13
-__device__ __forceinline__ int64_t token_pixel(int64_t t, int H, int W, int Hp, int Wp, int ws, bool* real) {
-    const int L = ws * ws;
-    const int nww = Wp / ws, nwh = Hp / ws;
-    const int tok = (int)(t % L);
-    const int64_t win = t / L;
-    const int ww = (int)(win % nww);
-    const int wh = (int)((win / nww) % nwh);
-    const int b = (int)(win / ((int64_t)nww * nwh));
-    const int h = wh * ws + tok / ws, w = ww * ws + tok % ws;
+__device__ __forceinline__ int64_t token_pixel(int64_t t64, int H, int W, int Hp, int Wp, int ws, bool* real) {
+    // token counts are < 2^31 (checked by the launchers): 32-bit division only
+    const uint32_t t = (uint32_t)t64, L = (uint32_t)(ws * ws), uws = (uint32_t)ws;
+    const uint32_t nww = (uint32_t)Wp / uws, nwh = (uint32_t)Hp / uws;
+    const uint32_t win = t / L, tok = t - win * L;
+    const uint32_t wrow = win / nww, ww = win - wrow * nww;
+    const uint32_t b = wrow / nwh, wh = wrow - b * nwh;
+    const uint32_t tr = tok / uws;
+    const int h = (int)(wh * uws + tr), w = (int)(ww * uws + (tok - tr * uws));
     *real = (h < H) && (w < W);
     return ((int64_t)b * H + h) * W + w;  // index in the UNPADDED image (valid only when *real)
 }
@@ -54,10 +54,11 @@ extern "C" int ymi_window_partition_index(int64_t n, int64_t hp, int64_t wp, int
 template <typename T, int DIR>
 __global__ void window_move_kernel(SV x, SV tok, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C) {
     const int groups = C / 4;
-    const int64_t total = Tn * groups;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const int64_t t = i / groups;
+    const uint32_t total = (uint32_t)(Tn * groups), ugroups = (uint32_t)groups;  // launcher: Tn * groups < 2^31
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t tu = i / ugroups;
+        const int g = (int)(i - tu * ugroups);
+        const int64_t t = tu;
         bool real;
         const int64_t px = token_pixel(t, H, W, Hp, Wp, ws, &real);
         if (DIR == 0) {
@@ -87,6 +88,7 @@ static int launch_window_move(const ymi_tensor* x, int64_t ws, const ymi_tensor*
     YMI_CHECK_ARG(ymi_pixels(tokens) == T && tokens->c == x->c && tokens->dtype == x->dtype, "%s: tokens must be [%lld, %lld]", what, (long long)T, (long long)x->c);
     YMI_CHECK_ARG(x->c % 4 == 0 && x->ld % 4 == 0 && tokens->ld % 4 == 0, "%s: channels multiple of 4", what);
     const int64_t total = T * (x->c / 4);
+    YMI_CHECK_ARG(total < (1ll << 31), "%s: tensor too large for 32-bit indexing", what);
     const unsigned gb = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
     SV xv{x->data, x->ld}, tv{tokens->data, tokens->ld};
     if (x->dtype == YMI_BF16)
@@ -371,7 +373,8 @@ __global__ __launch_bounds__(256) void window_attn_fwd_kernel(AttnArgs a) {
     T* out = reinterpret_cast<T*>(const_cast<void*>(a.out.p)) + t0 * a.out.ld;
     const int ndt = (a.hd + 15) / 16;
 
-    for (int head = 0; head < a.heads; ++head) {
+    {  // one (window, head) pair per workgroup: blockIdx.y = head
+        const int head = blockIdx.y;
         const int co = head * a.hd;
         lds_load_rows<T>(G1, qkv + co, a.qkv.ld, L, a.hd, hdp);            // Q
         lds_load_rows<T>(G2, qkv + a.C + co, a.qkv.ld, L, a.hd, hdp);      // K
@@ -458,7 +461,8 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(AttnArgs a) {
     T* dqkv = reinterpret_cast<T*>(const_cast<void*>(a.dqkv.p)) + t0 * a.dqkv.ld;
     const int ndt = (a.hd + 15) / 16;
 
-    for (int head = 0; head < a.heads; ++head) {
+    {  // one (window, head) pair per workgroup: blockIdx.y = head
+        const int head = blockIdx.y;
         const int co = head * a.hd;
         lds_load_rows<T>(G1, qkv + co, a.qkv.ld, L, a.hd, hdp);        // Q
         lds_load_rows<T>(G2, qkv + a.C + co, a.qkv.ld, L, a.hd, hdp);  // K
@@ -585,7 +589,7 @@ extern "C" int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int
     if (rc) return rc;
     YMI_CHECK_ARG(ymi_tensor_ok(out) && out->c == a.C && ymi_pixels(out) == ymi_pixels(qkv) && out->dtype == qkv->dtype, "window_attention_fwd: out");
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.lse = lse;
-    dim3 grid((unsigned)(ymi_pixels(qkv) / wlen));
+    dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
     if (qkv->dtype == YMI_BF16) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
@@ -609,7 +613,7 @@ extern "C" int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor*
     YMI_CHECK_ARG(ymi_pixels(out) == ymi_pixels(qkv) && ymi_pixels(dout) == ymi_pixels(qkv) && ymi_pixels(dqkv) == ymi_pixels(qkv), "window_attention_bwd: token counts");
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.dout = SV{dout->data, dout->ld}; a.dqkv = SV{dqkv->data, dqkv->ld};
     a.lse = const_cast<float*>(lse);
-    dim3 grid((unsigned)(ymi_pixels(qkv) / wlen));
+    dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
     if (qkv->dtype == YMI_BF16) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
