@@ -33,9 +33,9 @@ class Bottleneck(nn.Module):
         self.cv2 = Conv(c_, c2, k[1], 1, g=g)
         self.add = shortcut and c1 == c2
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = ops.to_internal(x)
-        return self.cv2(self.cv1(x), residual=x if self.add else None)
+        return self.cv2(self.cv1(x), residual=x if self.add else None, out=out)
 
 
 class C2f(nn.Module):
@@ -50,12 +50,20 @@ class C2f(nn.Module):
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
     def forward(self, x):
-        t, last = ops.c2f_split(self.cv1(x), self.c)  # (both chunks, second chunk): channel slices, no copy
+        x = ops.to_internal(x)
+        buf, slot = None, (lambda j: None)
+        dt = x.dtype
+        if self.training and hasattr(self.cv1, "bn") and self.c % ops.chunk_elems(dt) == 0:
+            # train mode: cv1 and every Bottleneck write straight into their slice of the concat buffer
+            n, _, h, w = x.shape
+            buf = ops.empty_nhwc(n, (2 + len(self.m)) * self.c, h, w, dt, x.device)
+            slot = lambda j: ops.OutSlot(buf, j * self.c)  # noqa: E731
+        t, last = ops.c2f_split(self.cv1(x, out=slot(0)), self.c)  # (both chunks, second chunk): channel slices, no copy
         ys = [t]  # both chunks go into the concat at once: they are adjacent in memory
-        for m in self.m:
-            last = m(last)
+        for j, m in enumerate(self.m):
+            last = m(last, out=slot(2 + j))
             ys.append(last)
-        return self.cv2(ops.concat(ys))
+        return self.cv2(ops.concat(ys, buf))
 
     forward_split = forward
 

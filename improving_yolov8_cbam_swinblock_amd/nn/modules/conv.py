@@ -51,21 +51,22 @@ class Conv(nn.Module):
             return ops.ACT_NONE
         raise NotImplementedError(f"activation {type(self.act).__name__} has no fused epilogue")
 
-    def forward(self, x, residual=None):
+    def forward(self, x, residual=None, out=None):
+        """out: optional ops.OutSlot (train mode only): write the result into a slice of a concat buffer."""
         x = ops.to_internal(x)
         k, s = self.conv.kernel_size[0], self.conv.stride[0]
         if not hasattr(self, "bn"):
             return self.forward_fuse(x, residual)
         if self.training:
-            return ops.conv_bn_act(x, self.conv.weight, self.bn, s, self._act_code(), residual)
+            return ops.conv_bn_act(x, self.conv.weight, self.bn, s, self._act_code(), residual, out)
         # eval: y = act(conv * scale + shift) with the running statistics, one kernel
         bn = self.bn
         scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
         shift = bn.bias - bn.running_mean * scale
         return ops.conv_affine_act(x, self.conv.weight, scale.float(), shift.float(), s, self._act_code(), residual)
 
-    def forward_fuse(self, x, residual=None):
-        """after fuse(): conv (with bias) -> act.  Reference conv.py:81-91."""
+    def forward_fuse(self, x, residual=None, out=None):
+        """after fuse(): conv (with bias) -> act.  Reference conv.py:81-91.  (`out` slots are a train-mode feature.)"""
         x = ops.to_internal(x)
         return ops.conv_affine_act(x, self.conv.weight, None, self.conv.bias, self.conv.stride[0], self._act_code(), residual)
 

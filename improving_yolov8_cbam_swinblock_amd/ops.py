@@ -249,12 +249,27 @@ def _dgrad(dy, weight4, k, stride, in_shape, dtype):
 
 
 # ------------------------------------------------------------------- Conv + BN(train) + act
+class OutSlot:
+    """where a producer writes its output: channels [off, off + c) of a pre-allocated NHWC concat buffer, so the
+    concat itself (block.py:304 `torch.cat`) needs no copy.  A plain Python object: the buffer is storage only and
+    never takes part in autograd; the producer's output is a view created inside its Function.forward."""
+
+    def __init__(self, buf, off):
+        self.buf, self.off = buf, int(off)
+
+    def view(self, n, c, h, w, dtype):
+        b = self.buf
+        if b.dtype != dtype or b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or self.off + c > b.shape[1]:
+            raise RuntimeError(f"output slot [{self.off}:{self.off + c}] of {tuple(b.shape)} {b.dtype} does not fit a {(n, c, h, w)} {dtype} result")
+        return b[:, self.off : self.off + c]
+
+
 class _ConvBnAct(torch.autograd.Function):
     """act(BatchNorm_train(conv(x))) (+ residual).  Reference: Conv.forward, nn/modules/conv.py:69-79
     (+ Bottleneck add, nn/modules/block.py:488)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum, act, residual):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum, act, residual, slot=None):
         dtype = x.dtype
         o, i, k, _ = weight.shape
         n, cp, h, w = x.shape
@@ -262,7 +277,7 @@ class _ConvBnAct(torch.autograd.Function):
         dev = x.device
         wp = pack_conv_fwd(weight, cp, dtype)
         raw = empty_nhwc(n, o, ho, wo, dtype, dev)
-        out = empty_nhwc(n, o, ho, wo, dtype, dev)
+        out = slot.view(n, o, ho, wo, dtype) if slot is not None else empty_nhwc(n, o, ho, wo, dtype, dev)
         stats = torch.empty((2, o), dtype=torch.float32, device=dev)
         m = n * ho * wo
         need = (L().ymi_conv2d_stat_blocks(m, o) * 2 * o + 2 * o) * 4
@@ -303,14 +318,14 @@ class _ConvBnAct(torch.autograd.Function):
             dx = _dgrad(draw, weight, k, stride, x.shape, dtype)
         dw, _ = _wgrad(x, draw, o, cin, k, stride, False)
         dres = dout if (has_res and ctx.needs_input_grad[10]) else None
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None
 
 
-def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None):
-    """train-mode Conv block on an internal (NHWC) tensor; updates bn.running_* in place."""
+def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
+    """train-mode Conv block on an internal (NHWC) tensor; updates bn.running_* in place.  slot: optional OutSlot."""
     if bn.momentum is None:
         raise RuntimeError("BatchNorm with cumulative moving average (momentum=None) is not supported")
-    out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual)
+    out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual, slot)
     if bn.num_batches_tracked is not None:
         if _deferred_counters is not None:
             _deferred_counters.append(bn.num_batches_tracked)
@@ -451,16 +466,20 @@ class _Concat(torch.autograd.Function):
     """channel concat by strided copies into one NHWC buffer (conv.py:683, block.py:226,304)."""
 
     @staticmethod
-    def forward(ctx, *xs):
+    def forward(ctx, buf, *xs):
         n, _, h, w = xs[0].shape
         cs = [t.shape[1] for t in xs]
-        out = empty_nhwc(n, sum(cs), h, w, xs[0].dtype, xs[0].device)
+        out = buf if buf is not None else empty_nhwc(n, sum(cs), h, w, xs[0].dtype, xs[0].device)
+        if out.shape[1] != sum(cs) or out.dtype != xs[0].dtype:
+            raise RuntimeError("concat buffer does not match its inputs")
         off = 0
         for t, c in zip(xs, cs):
-            check(L().ymi_copy(_byref(as_ymi(t)), _byref(as_ymi(out[:, off : off + c])), stream_ptr()), "copy")
+            dst = out[:, off : off + c]
+            if not (t.data_ptr() == dst.data_ptr() and t.stride() == dst.stride()):  # producers given an OutSlot already wrote here
+                check(L().ymi_copy(_byref(as_ymi(t)), _byref(as_ymi(dst)), stream_ptr()), "copy")
             off += c
         ctx.cs = cs
-        return out
+        return out if buf is None else out[:, :]
 
     @staticmethod
     def backward(ctx, g):
@@ -468,11 +487,12 @@ class _Concat(torch.autograd.Function):
         for c in ctx.cs:
             outs.append(g[:, off : off + c])
             off += c
-        return tuple(outs)
+        return (None, *outs)
 
 
-def concat(xs):
-    return _Concat.apply(*xs)
+def concat(xs, buf=None):
+    """channel concat; buf: optional pre-allocated NHWC buffer whose slices some inputs already alias (OutSlot)."""
+    return _Concat.apply(buf, *xs)
 
 
 class _C2fSplit(torch.autograd.Function):
