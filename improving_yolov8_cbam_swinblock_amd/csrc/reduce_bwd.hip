@@ -3,6 +3,8 @@
 // All reductions are two-stage and deterministic: stage 1 gives every workgroup a contiguous pixel
 // range and a fixed channel group per thread (coalesced 8/16-byte reads along C), accumulates in f32
 // registers and writes [block][2][C] partials; stage 2 sums the partials per channel in double.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct RV {
@@ -102,7 +104,19 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
 
 // stage 2: out0[c] = sum_b part[b][0][c], out1[c] = sum_b part[b][1][c]
 // 32 channels x 32 row slices per block, 4 independent accumulator pairs per thread (loads in flight)
-__global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1) {
+// coefficients of the BN backward apply pass, from the finished sums (one set per channel):
+//   z = x*a0 + a1 ;  draw = dy*act'(z)*c0 - x*c1 - c2
+struct BnCoefArgs {
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* inv;
+    float inv_count;
+    float* coef;  // [5][C] or nullptr
+};
+
+__global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1,
+                                                                 BnCoefArgs bn) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -139,6 +153,16 @@ __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __
         }
         if (out0) out0[c] = (float)a;
         if (out1) out1[c] = (float)b2;
+        if (bn.coef) {
+            const float ga = bn.gamma ? bn.gamma[c] : 1.0f, be = bn.beta ? bn.beta[c] : 0.0f;
+            const float p0 = bn.inv[c], p1 = -bn.mean[c] * p0;
+            const float k1 = (float)a * bn.inv_count, k2 = (float)b2 * bn.inv_count;
+            bn.coef[0 * C + c] = p0 * ga;
+            bn.coef[1 * C + c] = p1 * ga + be;
+            bn.coef[2 * C + c] = ga * p0;
+            bn.coef[3 * C + c] = ga * p0 * p0 * k2;
+            bn.coef[4 * C + c] = ga * p0 * (k1 + p1 * k2);
+        }
     }
 }
 
@@ -184,7 +208,7 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
 }
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream) {
-    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, blocks, C, out0, out1);
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, blocks, C, out0, out1, BnCoefArgs{});
     YMI_CHECK_LAUNCH("chan_reduce_final");
     return YMI_OK;
 }
@@ -216,58 +240,54 @@ int ymi_ln_param_grads(const ymi_tensor* dy, const ymi_tensor* x, const float* m
     return ymi_chan_reduce_final((const float*)workspace, blocks, (int)dy->c, dbeta, dgamma, stream);
 }
 
-// draw = gamma*inv*(dz - mean(dz) - xhat*mean(dz*xhat))
-// FIXED: the number of 4-channel groups divides 256, so a thread keeps one channel group and its
-// per-channel coefficients in registers for all of its pixels.
-template <typename T, bool FIXED, int ACT>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t P, int C, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, const float* __restrict__ mean,
-                                                               const float* __restrict__ inv, const float* __restrict__ sum_dz,
-                                                               const float* __restrict__ sum_dzx, float inv_count) {
-    const int groups = C / 4;
+// draw = gamma*inv*(dz - mean(dz) - xhat*mean(dz*xhat)), dz = dy*act'(z), written with the per-channel coefficients the
+// final-reduce kernel prepared:  z = x*a0 + a1 ;  draw = dz*c0 - x*c1 - c2   (coef = [a0|a1|c0|c1|c2][C])
+// FIXED: the number of G-channel groups divides 256, so a thread keeps one channel group and its coefficients in
+// registers for all of its pixels.  G = 4 (8-byte bf16 / 16-byte f32 accesses) or 8 (bf16 only, 16-byte accesses).
+template <typename T, int G, bool FIXED, int ACT>
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t P, int C, const float* __restrict__ coef) {
+    const int groups = C / G;
     const T* dp = reinterpret_cast<const T*>(dout.p);
     const T* rp = reinterpret_cast<const T*>(raw.p);
     T* op = reinterpret_cast<T*>(const_cast<void*>(draw.p));
     if constexpr (FIXED) {
         const int g = threadIdx.x % groups, rows = 256 / groups;
-        float ga[4], be[4], p0[4], p1[4], k1[4], k2[4];
+        float a0[G], a1[G], c0[G], c1[G], c2[G];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = g * 4 + r;
-            ga[r] = gamma ? gamma[c] : 1.0f;
-            be[r] = beta ? beta[c] : 0.0f;
-            p0[r] = inv[c];
-            p1[r] = -mean[c] * inv[c];
-            k1[r] = sum_dz[c] * inv_count;
-            k2[r] = sum_dzx[c] * inv_count;
+        for (int r = 0; r < G; ++r) {
+            const int c = g * G + r;
+            a0[r] = coef[c];
+            a1[r] = coef[C + c];
+            c0[r] = coef[2 * C + c];
+            c1[r] = coef[3 * C + c];
+            c2[r] = coef[4 * C + c];
         }
-        auto one = [&](const float (&d)[4], const float (&x)[4], int64_t p) {
-            float o[4];
+        auto one = [&](const float (&d)[G], const float (&x)[G], int64_t p) {
+            float o[G];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float xh = x[r] * p0[r] + p1[r];
-                const float dz = d[r] * act_grad<ACT>(xh * ga[r] + be[r]);
-                o[r] = ga[r] * p0[r] * (dz - k1[r] - xh * k2[r]);
+            for (int r = 0; r < G; ++r) {
+                const float dz = d[r] * act_grad<ACT>(x[r] * a0[r] + a1[r]);
+                o[r] = dz * c0[r] - (x[r] * c1[r] + c2[r]);
             }
-            Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
+            Pack<T, G>::store(op + p * draw.ld + g * G, o);
         };
+        constexpr int U = G == 8 ? 2 : 4;  // pixels per trip: 2*U independent loads in flight per lane
         const int64_t step = (int64_t)gridDim.x * rows;
         int64_t p = (int64_t)blockIdx.x * rows + threadIdx.x / groups;
-        // 4 pixels per trip: 8 independent loads in flight per lane before the first use
-        for (; p + 3 * step < P; p += 4 * step) {
-            float d[4][4], x[4][4];
+        for (; p + (U - 1) * step < P; p += U * step) {
+            float d[U][G], x[U][G];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                Pack<T, 4>::load(dp + (p + u * step) * dout.ld + g * 4, d[u]);
-                Pack<T, 4>::load(rp + (p + u * step) * raw.ld + g * 4, x[u]);
+            for (int u = 0; u < U; ++u) {
+                Pack<T, G>::load(dp + (p + u * step) * dout.ld + g * G, d[u]);
+                Pack<T, G>::load(rp + (p + u * step) * raw.ld + g * G, x[u]);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) one(d[u], x[u], p + u * step);
+            for (int u = 0; u < U; ++u) one(d[u], x[u], p + u * step);
         }
         for (; p < P; p += step) {
-            float d[4], x[4];
-            Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
-            Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+            float d[G], x[G];
+            Pack<T, G>::load(dp + p * dout.ld + g * G, d);
+            Pack<T, G>::load(rp + p * raw.ld + g * G, x);
             one(d, x, p);
         }
     } else {
@@ -276,18 +296,16 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
             const uint32_t pu = i / ugroups;
             const int g = (int)(i - pu * ugroups);
             const int64_t p = pu;
-            float d[4], x[4], o[4];
-            Pack<T, 4>::load(dp + p * dout.ld + g * 4, d);
-            Pack<T, 4>::load(rp + p * raw.ld + g * 4, x);
+            float d[G], x[G], o[G];
+            Pack<T, G>::load(dp + p * dout.ld + g * G, d);
+            Pack<T, G>::load(rp + p * raw.ld + g * G, x);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = g * 4 + r;
-                const float ga = gamma ? gamma[c] : 1.0f, be = beta ? beta[c] : 0.0f;
-                const float xh = (x[r] - mean[c]) * inv[c];
-                const float dz = d[r] * act_grad<ACT>(xh * ga + be);
-                o[r] = ga * inv[c] * (dz - sum_dz[c] * inv_count - xh * sum_dzx[c] * inv_count);
+            for (int r = 0; r < G; ++r) {
+                const int c = g * G + r;
+                const float dz = d[r] * act_grad<ACT>(x[r] * coef[c] + coef[C + c]);
+                o[r] = dz * coef[2 * C + c] - (x[r] * coef[3 * C + c] + coef[4 * C + c]);
             }
-            Pack<T, 4>::store(op + p * draw.ld + g * 4, o);
+            Pack<T, G>::store(op + p * draw.ld + g * G, o);
         }
     }
 }
@@ -302,7 +320,8 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     YMI_CHECK_ARG(draw->ld % 4 == 0, "bn_act_bwd: draw ld");
     const int64_t P = ymi_pixels(dout);
     const int C = (int)dout->c;
-    const size_t need = (size_t)reduce_blocks(P) * 2 * C * sizeof(float);
+    const int rblocks = reduce_blocks(P);
+    const size_t need = ((size_t)rblocks * 2 * C + 5 * (size_t)C) * sizeof(float);
     if (workspace_bytes < need) {
         ymi_set_error("bn_act_bwd: workspace %zu < %zu", workspace_bytes, need);
         return YMI_EWORKSPACE;
@@ -311,29 +330,45 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     int blocks = 0;
     int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)");
     if (rc) return rc;
-    rc = ymi_chan_reduce_final((const float*)workspace, blocks, C, dbeta, dgamma, s);  // dbeta = sum dz, dgamma = sum dz*xhat
-    if (rc) return rc;
-    const int groups = C / 4;
+    float* coef = (float*)workspace + (size_t)blocks * 2 * C;
+    // dbeta = sum dz, dgamma = sum dz*xhat, and the apply pass's coefficients
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)workspace, blocks, C, dbeta, dgamma,
+                       BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef});
+    YMI_CHECK_LAUNCH("bn_act_bwd(final)");
+    const bool bf = dout->dtype == YMI_BF16;
+    const bool al16 = bf && C % 8 == 0 && dout->ld % 8 == 0 && raw->ld % 8 == 0 && draw->ld % 8 == 0 &&
+                      (((uintptr_t)dout->data | (uintptr_t)raw->data | (uintptr_t)draw->data) & 15) == 0;
+    static const int g8_env = getenv("YMI_BN_APPLY8") ? atoi(getenv("YMI_BN_APPLY8")) : 0;  // tuning knob: 1 = 16-byte (8-channel) groups for bf16; measured equal to the 8-byte form
+    const int G = (al16 && g8_env && C / 8 <= 256 && 256 % (C / 8) == 0) ? 8 : 4;
+    const int groups = C / G;
     const bool fixed = groups <= 256 && 256 % groups == 0;
     const int64_t total = P * groups;
     YMI_CHECK_ARG(total < (1ll << 31), "bn_act_bwd: tensor too large for 32-bit indexing");
-    int64_t gb = fixed ? (P + 256 / groups - 1) / (256 / groups) : (total + 255) / 256;
+    int64_t gb;
+    if (fixed) {
+        // every thread reloads its group's coefficients: give it at least ~8 pixels when the tensor allows
+        const int rows = 256 / groups;
+        gb = (P + (int64_t)rows * 8 - 1) / ((int64_t)rows * 8);
+        if (gb < 256) gb = (P + rows - 1) / rows < 256 ? (P + rows - 1) / rows : 256;
+    } else {
+        gb = (total + 255) / 256;
+    }
     if (gb > 2048) gb = 2048;
     RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
-    const float ic = 1.0f / (float)P;
-#define YMI_BWD_APPLY(T, F, A) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, F, A>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, gamma, beta, save_mean, save_invstd, dbeta, dgamma, ic)
-#define YMI_BWD_APPLY_A(T, F)                                     \
-    do {                                                          \
-        if (act == YMI_ACT_SILU) YMI_BWD_APPLY(T, F, YMI_ACT_SILU); \
-        else if (act == YMI_ACT_GELU) YMI_BWD_APPLY(T, F, YMI_ACT_GELU); \
-        else YMI_BWD_APPLY(T, F, YMI_ACT_NONE);                   \
+#define YMI_BWD_APPLY(T, GG, F, A) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, GG, F, A>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, coef)
+#define YMI_BWD_APPLY_A(T, GG, F)                                          \
+    do {                                                                   \
+        if (act == YMI_ACT_SILU) YMI_BWD_APPLY(T, GG, F, YMI_ACT_SILU);      \
+        else if (act == YMI_ACT_GELU) YMI_BWD_APPLY(T, GG, F, YMI_ACT_GELU); \
+        else YMI_BWD_APPLY(T, GG, F, YMI_ACT_NONE);                         \
     } while (0)
-    if (dout->dtype == YMI_BF16) {
-        if (fixed) YMI_BWD_APPLY_A(bf16_t, true);
-        else YMI_BWD_APPLY_A(bf16_t, false);
+    if (bf) {
+        if (G == 8) YMI_BWD_APPLY_A(bf16_t, 8, true);
+        else if (fixed) YMI_BWD_APPLY_A(bf16_t, 4, true);
+        else YMI_BWD_APPLY_A(bf16_t, 4, false);
     } else {
-        if (fixed) YMI_BWD_APPLY_A(float, true);
-        else YMI_BWD_APPLY_A(float, false);
+        if (fixed) YMI_BWD_APPLY_A(float, 4, true);
+        else YMI_BWD_APPLY_A(float, 4, false);
     }
 #undef YMI_BWD_APPLY_A
 #undef YMI_BWD_APPLY
