@@ -37,8 +37,11 @@ typedef __attribute__((ext_vector_type(4))) short s16x4;
 
 constexpr int WG_BM = 64;    // rows  (co)
 constexpr int WG_BN = 128;   // cols  ((tap, ci))
-constexpr int WG_BK = 32;    // pixels per K step
+constexpr int WG_BK = 32;    // pixels per K step (64 was measured 10-15 % slower: half as many resident workgroups per CU)
 
+#ifndef YMI_WGRAD_WAVES
+#define YMI_WGRAD_WAVES 5  // waves per SIMD the register allocation must allow (the kernel is latency-bound: occupancy pays)
+#endif
 template <typename T> struct WFrag;
 // LDS bank swizzle for the transposed reads (bf16).  ds_read_b64_tr_b16 is serviced per 32-lane half: 2 groups x
 // (4 rows x 4 eight-byte units); the 8 rows of a half are {r0..r0+3, r0+8..r0+11}.  With 128-byte (dY) or 256-byte
@@ -65,15 +68,20 @@ template <> struct WFrag<bf16_t> {
     }
     template <int TR, int TC>
     static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
-        bf16x8 af[TR], bfr[TC];
 #pragma unroll
-        for (int t = 0; t < TR; ++t) af[t] = load<false>(Ys, WG_BM * 2, r0 + t * 16, lane);
+        for (int ks = 0; ks < WG_BK / 32; ++ks) {  // pixel rows 32*ks .. 32*ks+31 (the swizzles use row bits 0..3 only)
+            const char* Yk = Ys + ks * 32 * WG_BM * 2;
+            const char* Xk = Xs + ks * 32 * WG_BN * 2;
+            bf16x8 af[TR], bfr[TC];
 #pragma unroll
-        for (int t = 0; t < TC; ++t) bfr[t] = load<true>(Xs, WG_BN * 2, c0 + t * 16, lane);
+            for (int t = 0; t < TR; ++t) af[t] = load<false>(Yk, WG_BM * 2, r0 + t * 16, lane);
 #pragma unroll
-        for (int a = 0; a < TR; ++a)
+            for (int t = 0; t < TC; ++t) bfr[t] = load<true>(Xk, WG_BN * 2, c0 + t * 16, lane);
 #pragma unroll
-            for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < TR; ++a)
+#pragma unroll
+                for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+        }
     }
 };
 template <> struct WFrag<float> {
@@ -96,7 +104,7 @@ template <> struct WFrag<float> {
 };
 
 template <typename T, int NS>
-__global__ __launch_bounds__(256) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
     constexpr int YCW = WG_BM * ES / 16, XCW = WG_BN * ES / 16;        // 16-byte chunks per tile row
@@ -319,13 +327,17 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     if (x->dtype == YMI_BF16) {
         static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
         const size_t lds = (size_t)ns * (size_t)(WG_BK * (WG_BM + WG_BN) * 2);
+        if (ns > 2) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
         if (ns == 4) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 4>), grid, dim3(256), lds, s, a);
         else if (ns == 3) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3>), grid, dim3(256), lds, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2>), grid, dim3(256), lds, s, a);
     } else {
-        const size_t lds = 3 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        hipLaunchKernelGGL((wgrad_kernel<float, 3>), grid, dim3(256), lds, s, a);
+        const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<float, 2>), grid, dim3(256), lds, s, a);
     }
     ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");
