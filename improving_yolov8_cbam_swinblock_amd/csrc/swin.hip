@@ -10,6 +10,8 @@
 //    ds_read_b128 fragment reads are conflict-free); 49 tokens pad to 64 with zero rows, pad keys
 //    masked to -inf before the softmax; V (and, in backward, dO / Q / K) are transposed on the way
 //    into LDS.  Token GEMMs (QKV, proj, MLP) are ymi_conv2d_fwd with a 1x1 "kernel".
+#include <stdlib.h>
+
 #include "common.h"
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream);
@@ -560,6 +562,228 @@ __global__ __launch_bounds__(256) void window_attn_bwd_kernel(AttnArgs a) {
     }
 }
 
+// ---- bf16 backward with hardware-transposed fragment reads -------------------------------------------------------
+// Q, K, V, dO of one (window, head) are staged ONCE, row-major; P and dS are written row-major; every product whose
+// reduction index is the slow (row) index of an LDS image takes its fragments with ds_read_b64_tr_b16, so no operand
+// is loaded from HBM a second time in transposed form and the kernel has two workgroup barriers instead of twelve.
+typedef __attribute__((ext_vector_type(4))) short at_s16x4;
+typedef __attribute__((ext_vector_type(8))) short at_s16x8;
+// 8 k-values (rows k0 + 8*(lane>>4) .. +7) of column c0 + (lane&15) from a K-major image img[k][col]
+__device__ __forceinline__ bf16x8 attn_tr_frag(const char* img, int rowb, int k0, int c0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const int r_lo = k0 + 8 * g + q, r_hi = r_lo + 4;
+    const int u = (c0 >> 2) + p;  // 8-byte unit holding this lane's 4 columns
+    const at_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(img + (size_t)r_lo * rowb + u * 8));
+    const at_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) at_s16x4*)(img + (size_t)r_hi * rowb + u * 8));
+    const at_s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// stage NM [L][hd] bf16 matrices as zero-padded [64][hdp+8] LDS images: all global loads of a round are issued before
+// the first LDS store (these kernels are latency-bound: a load->store round per matrix costs more than the arithmetic)
+template <int NM>
+__device__ __forceinline__ void attn_stage_rows(const bf16_t* const (&srcs)[NM], const int64_t (&lds_)[NM], char* const (&dsts)[NM], int L, int hd, int hdp) {
+    const int g4 = hdp / 4, items = 64 * g4, rstride = (hdp + 8) * 2;
+    for (int base = threadIdx.x; base < items; base += 512) {
+        bf16x4 v[2][NM];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = base + 256 * u;
+            const int r = i / g4, c = (i - r * g4) * 4;
+            const bool ok = i < items && r < L && c < hd;
+#pragma unroll
+            for (int mtx = 0; mtx < NM; ++mtx)
+                v[u][mtx] = ok ? *reinterpret_cast<const bf16x4*>(srcs[mtx] + (int64_t)r * lds_[mtx] + c) : bf16x4{(bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f, (bf16_t)0.f};
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int i = base + 256 * u;
+            const int r = i / g4, c = (i - r * g4) * 4;
+            if (i < items) {
+#pragma unroll
+                for (int mtx = 0; mtx < NM; ++mtx) *reinterpret_cast<bf16x4*>(dsts[mtx] + (size_t)r * rstride + c * 2) = v[u][mtx];
+            }
+        }
+    }
+}
+
+// bf16 forward: Q, K, V staged once row-major; O = P V takes V through transposed fragment reads
+__global__ __launch_bounds__(256) void window_attn_fwd_tr_kernel(AttnArgs a) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int hdp = a.hdp, L = a.L;
+    const int rstride = (hdp + 8) * 2, tstride = (64 + 8) * 2;
+    char* Qs = smem;
+    char* Ks = Qs + (size_t)64 * rstride;
+    char* Vs = Ks + (size_t)64 * rstride;
+    char* P = Vs + (size_t)64 * rstride;  // [query][key]
+    const int head = blockIdx.y;
+    const int co = head * a.hd;
+    const int64_t t0 = (int64_t)blockIdx.x * L;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
+    T* out = reinterpret_cast<T*>(const_cast<void*>(a.out.p)) + t0 * a.out.ld;
+    const int ndt = (a.hd + 15) / 16;
+    {
+        const bf16_t* srcs[3] = {qkv + co, qkv + a.C + co, qkv + 2 * a.C + co};
+        const int64_t lds_[3] = {a.qkv.ld, a.qkv.ld, a.qkv.ld};
+        char* dsts[3] = {Qs, Ks, Vs};
+        attn_stage_rows<3>(srcs, lds_, dsts, L, a.hd, hdp);
+    }
+    __syncthreads();
+    // S^T tiles: A = K rows (i = key), B = Q rows (j = query): this wave owns queries 16*wv..+15
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        AT<T>::mma(Ks, rstride, t * 16, Qs, rstride, wv * 16, hdp, lane, s[t]);
+    }
+    // lane holds query m = 16*wv + l15, keys j = 16t + 4*l4 + r
+    float mx = -__builtin_inff();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * t + 4 * l4 + r;
+            s[t][r] = j < L ? s[t][r] * a.scale : -__builtin_inff();
+            mx = fmaxf(mx, s[t][r]);
+        }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    float sum = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            s[t][r] = __expf(s[t][r] - mx);
+            sum += s[t][r];
+        }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.f / sum;
+    const int m = 16 * wv + l15;
+    if (l4 == 0 && m < L && a.lse) a.lse[(t0 + m) * a.heads + head] = mx + __logf(sum);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float p[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[r] = s[t][r] * inv;
+        Pack<T, 4>::store(reinterpret_cast<T*>(P + (size_t)m * tstride) + 16 * t + 4 * l4, p);
+    }
+    __syncthreads();
+    // O[m][d] = sum_j P[m][j] V[j][d]: A = rows of P (k = j contiguous), B = transposed read of V
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt)
+        if (dt < ndt) {
+            f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 32) {
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(P + (size_t)(16 * wv + l15) * tstride + (k0 + 8 * l4) * 2);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, attn_tr_frag(Vs, rstride, k0, 16 * dt, lane), o, 0, 0, 0);
+            }
+            const int d = dt * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mq = wv * 16 + 4 * l4 + r;
+                if (mq < L && d < a.hd) out[(int64_t)mq * a.out.ld + co + d] = (T)o[r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void window_attn_bwd_tr_kernel(AttnArgs a) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int hdp = a.hdp, L = a.L;
+    const int rstride = (hdp + 8) * 2, tstride = (64 + 8) * 2;
+    char* Qs = smem;
+    char* Ks = Qs + (size_t)64 * rstride;
+    char* Vs = Ks + (size_t)64 * rstride;
+    char* Os = Vs + (size_t)64 * rstride;   // dO
+    char* Ps = Os + (size_t)64 * rstride;   // P  [query][key]
+    char* Ds = Ps + (size_t)64 * tstride;   // dS [query][key] (scale folded in)
+    const int head = blockIdx.y;
+    const int co = head * a.hd;
+    const int64_t t0 = (int64_t)blockIdx.x * L;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
+    const T* dO = reinterpret_cast<const T*>(a.dout.p) + t0 * a.dout.ld;
+    T* dqkv = reinterpret_cast<T*>(const_cast<void*>(a.dqkv.p)) + t0 * a.dqkv.ld;
+    const int ndt = (a.hd + 15) / 16;
+
+    {
+        const bf16_t* srcs[4] = {qkv + co, qkv + a.C + co, qkv + 2 * a.C + co, dO + co};
+        const int64_t lds_[4] = {a.qkv.ld, a.qkv.ld, a.qkv.ld, a.dout.ld};
+        char* dsts[4] = {Qs, Ks, Vs, Os};
+        attn_stage_rows<4>(srcs, lds_, dsts, L, a.hd, hdp);
+    }
+    __syncthreads();
+    // this wave owns queries 16*wv..+15: S = Q K^T and dP = dO V^T against the four key tiles
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        AT<T>::mma(Qs, rstride, wv * 16, Ks, rstride, t * 16, hdp, lane, s[t]);
+        AT<T>::mma(Os, rstride, wv * 16, Vs, rstride, t * 16, hdp, lane, dp[t]);
+    }
+    // lane holds queries m = 16*wv + 4*l4 + r, keys j = 16*t + l15
+    float pr[4][4], delta[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 16 * wv + 4 * l4 + r;
+        const float lse = m < L ? a.lse[(t0 + m) * a.heads + head] : 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = (16 * t + l15 < L) && (m < L);
+            pr[t][r] = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
+            delta[r] += pr[t][r] * dp[t][r];  // sum_j P dP = dO . O   (row sum: finished by the 16-lane reduction below)
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) delta[r] += __shfl_xor(delta[r], o, 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int j = 16 * t + l15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = 16 * wv + 4 * l4 + r;
+            const float ds = pr[t][r] * (dp[t][r] - delta[r]) * a.scale;
+            reinterpret_cast<T*>(Ps + (size_t)m * tstride)[j] = (T)pr[t][r];
+            reinterpret_cast<T*>(Ds + (size_t)m * tstride)[j] = (T)ds;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt)
+        if (dt < ndt) {
+            f32x4 dv = f32x4{0.f, 0.f, 0.f, 0.f}, dk = dv, dq = dv;
+#pragma unroll
+            for (int k0 = 0; k0 < 64; k0 += 32) {
+                // dV[j][d] = sum_m P[m][j] dO[m][d] ; dK[j][d] = sum_m dS[m][j] Q[m][d]   (k = m: both operands transposed reads)
+                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Ps, tstride, k0, 16 * wv, lane), attn_tr_frag(Os, rstride, k0, 16 * dt, lane), dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Ds, tstride, k0, 16 * wv, lane), attn_tr_frag(Qs, rstride, k0, 16 * dt, lane), dk, 0, 0, 0);
+                // dQ[m][d] = sum_j dS[m][j] K[j][d]   (A: rows of dS, k = j contiguous; B: transposed read of K)
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ds + (size_t)(16 * wv + l15) * tstride + (k0 + 8 * l4) * 2);
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, attn_tr_frag(Ks, rstride, k0, 16 * dt, lane), dq, 0, 0, 0);
+            }
+            const int d = dt * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wv * 16 + 4 * l4 + r;  // key j for dV/dK, query m for dQ
+                if (row < L && d < a.hd) {
+                    T* dst = dqkv + (int64_t)row * a.dqkv.ld + co + d;
+                    dst[2 * a.C] = (T)dv[r];
+                    dst[a.C] = (T)dk[r];
+                    dst[0] = (T)dq[r];
+                }
+            }
+        }
+}
+
 static int attn_common(const ymi_tensor* qkv, int64_t wlen, int64_t heads, AttnArgs* a, size_t* lds, bool bwd, const char* what) {
     YMI_CHECK_ARG(ymi_tensor_ok(qkv) && wlen > 0 && heads > 0, "%s: args", what);
     YMI_CHECK_ARG(qkv->c % 3 == 0, "%s: qkv must have 3C channels", what);
@@ -590,7 +814,12 @@ extern "C" int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int
     YMI_CHECK_ARG(ymi_tensor_ok(out) && out->c == a.C && ymi_pixels(out) == ymi_pixels(qkv) && out->dtype == qkv->dtype, "window_attention_fwd: out");
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.lse = lse;
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
-    if (qkv->dtype == YMI_BF16) {
+    static const int attn_tr = getenv("YMI_ATTN_TR") ? atoi(getenv("YMI_ATTN_TR")) : 1;  // 0: the generic (f32-style) kernel for bf16 too
+    const size_t lds_tr = (size_t)3 * 64 * (a.hdp + 8) * 2 + (size_t)64 * (64 + 8) * 2;
+    if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(window_attn_fwd_tr_kernel, grid, dim3(256), lds_tr, (hipStream_t)stream, a);
+    } else if (qkv->dtype == YMI_BF16) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
     } else {
@@ -614,7 +843,12 @@ extern "C" int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor*
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.dout = SV{dout->data, dout->ld}; a.dqkv = SV{dqkv->data, dqkv->ld};
     a.lse = const_cast<float*>(lse);
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
-    if (qkv->dtype == YMI_BF16) {
+    static const int attn_tr = getenv("YMI_ATTN_TR") ? atoi(getenv("YMI_ATTN_TR")) : 1;  // 0: the generic (f32-style) kernel for bf16 too
+    const size_t lds_tr = (size_t)4 * 64 * (a.hdp + 8) * 2 + (size_t)2 * 64 * (64 + 8) * 2;
+    if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(window_attn_bwd_tr_kernel, grid, dim3(256), lds_tr, (hipStream_t)stream, a);
+    } else if (qkv->dtype == YMI_BF16) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_bwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
     } else {
