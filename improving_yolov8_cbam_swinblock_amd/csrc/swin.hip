@@ -184,7 +184,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ part, int accumulate) {
-    __shared__ float red[4][2][1024];
+    extern __shared__ float red_dyn[];  // [4 waves][2][Cr], Cr = C rounded up to 256: sized by the launcher, so 8+ workgroups fit a CU
+    const int Cr = (C + 255) / 256 * 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float ag[LN_MAXG][4], ab[LN_MAXG][4], g[LN_MAXG][4];
 #pragma unroll
@@ -252,19 +253,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, 
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = lane * 4 + 256 * i + r;
-            red[wv][0][c] = ab[i][r];
-            red[wv][1][c] = ag[i][r];
+            if (c < Cr) {
+                red_dyn[(wv * 2 + 0) * Cr + c] = ab[i][r];
+                red_dyn[(wv * 2 + 1) * Cr + c] = ag[i][r];
+            }
         }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
-        part[((int64_t)blockIdx.x * 2 + 0) * C + c] = red[0][0][c] + red[1][0][c] + red[2][0][c] + red[3][0][c];
-        part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red[0][1][c] + red[1][1][c] + red[2][1][c] + red[3][1][c];
+        part[((int64_t)blockIdx.x * 2 + 0) * C + c] = red_dyn[0 * Cr + c] + red_dyn[2 * Cr + c] + red_dyn[4 * Cr + c] + red_dyn[6 * Cr + c];
+        part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red_dyn[1 * Cr + c] + red_dyn[3 * Cr + c] + red_dyn[5 * Cr + c] + red_dyn[7 * Cr + c];
     }
 }
 
 static int ln_bwd_blocks(int64_t T) {
     int64_t b = (T + 31) / 32;  // >= 8 tokens per wave
-    if (b > 512) b = 512;
+    if (b > 2048) b = 2048;     // the token loop is a serial load -> reduce -> store chain: many resident waves hide it
     if (b < 1) b = 1;
     return (int)b;
 }
@@ -287,10 +290,11 @@ extern "C" int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tens
     }
     SV xv{x->data, x->ld}, dv{dout->data, dout->ld}, ov{dx->data, dx->ld};
     hipStream_t s = (hipStream_t)stream;
+    const size_t red_bytes = (size_t)8 * ((x->c + 255) / 256 * 256) * sizeof(float);
     if (x->dtype == YMI_BF16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), 0, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
+        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), red_bytes, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), 0, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
+        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), red_bytes, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
     YMI_CHECK_LAUNCH("layernorm_bwd");
     return ymi_chan_reduce_final((const float*)workspace, blocks, (int)x->c, dbeta, dgamma, s);
 }

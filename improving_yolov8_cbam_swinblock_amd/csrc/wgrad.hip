@@ -238,8 +238,9 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
         float s = 0.f;
 #pragma unroll
         for (int q = 0; q < 32; ++q) s += red[q][ol];
-        const int co = (int)(e / NG), col = (int)(e % NG);
-        const int tap = col / Cin, ci = col % Cin;
+        const uint32_t eu = (uint32_t)e;  // < 2^31
+        const int co = (int)(eu / (uint32_t)NG), col = (int)(eu - (uint32_t)co * (uint32_t)NG);
+        const int tap = (int)((uint32_t)col / (uint32_t)Cin), ci = col - tap * Cin;
         if (co < cout_real && ci < cin_real) dw[((int64_t)co * cin_real + ci) * ntaps + tap] = s;
     }
 }
@@ -247,16 +248,26 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 // few splits (large weight matrices): one thread per output element, coalesced along (tap, ci)
 __global__ void wgrad_reduce_small_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real, int cin_real,
                                           int ntaps, float* __restrict__ dw) {
-    const int64_t total = (int64_t)cout_real * ntaps * cin_real;
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * blockDim.x) {
-        const int ci = (int)(idx % cin_real);
-        int64_t t = idx / cin_real;
-        const int tap = (int)(t % ntaps);
-        const int co = (int)(t / ntaps);
-        const int64_t off = (int64_t)co * NG + tap * Cin + ci;
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += slab[(int64_t)k * CoutP * NG + off];
-        dw[((int64_t)co * cin_real + ci) * ntaps + tap] = s;
+    // 32-bit index arithmetic (a weight tensor has < 2^31 elements); four independent partial sums keep the split
+    // loads in flight, combined in a fixed order (deterministic)
+    const uint32_t total = (uint32_t)cout_real * (uint32_t)ntaps * (uint32_t)cin_real;
+    const int64_t sstride = (int64_t)CoutP * NG;
+    for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const uint32_t t = idx / (uint32_t)cin_real;
+        const uint32_t ci = idx - t * (uint32_t)cin_real;
+        const uint32_t co = t / (uint32_t)ntaps;
+        const uint32_t tap = t - co * (uint32_t)ntaps;
+        const float* p = slab + (int64_t)co * NG + tap * Cin + ci;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < splits; k += 4) {
+            s0 += p[(int64_t)k * sstride];
+            s1 += p[(int64_t)(k + 1) * sstride];
+            s2 += p[(int64_t)(k + 2) * sstride];
+            s3 += p[(int64_t)(k + 3) * sstride];
+        }
+        for (; k < splits; ++k) s0 += p[(int64_t)k * sstride];
+        dw[((int64_t)co * cin_real + ci) * ntaps + tap] = (s0 + s1) + (s2 + s3);
     }
 }
 

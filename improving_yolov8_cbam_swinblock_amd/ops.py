@@ -674,7 +674,7 @@ class _LayerNorm(torch.autograd.Function):
         c = x.shape[1]
         dx = empty_nhwc(*x.shape, x.dtype, dev) if ws > 0 else torch.empty_like(x)
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
-        wsb = workspace(512 * 2 * c * 4 + 256, dev, "ln")
+        wsb = workspace(2048 * 2 * c * 4 + 256, dev, "ln")
         check(
             L().ymi_layernorm_bwd(_byref(as_ymi(x)), ws, _byref(as_ymi(g)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), _byref(as_ymi(dx)), 0,
                                   ptr(dgb[0]), ptr(dgb[1]), ptr(wsb), wsb.numel(), stream_ptr()),
