@@ -49,6 +49,7 @@ struct IgemmArgs {
     uint64_t tap_dh, tap_dw;
     int act, vec_store, vec16;
     uint32_t wo_mul, wo_shr, ho_mul, ho_shr;  // fast division by Wo / Ho
+    int nmb, nnb, mpx;                        // M blocks, N blocks, M blocks per XCD (launch geometry, set by the launcher)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -125,15 +126,16 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
     const int wm = wave / WN, wn = wave % WN;
-    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs, so give each XCD a CONTIGUOUS range of
-    // M blocks (neighbouring pixel tiles share 3x3 halo rows and hit the same L2).  Bijective for any grid size.
-    int mb;
-    {
-        const int nmb = gridDim.x, orig = blockIdx.x;
-        const int q = nmb >> 3, r = nmb & 7, xcd = orig & 7;
-        mb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
-    }
-    const int m0 = mb * BM, n0 = blockIdx.y * BN;
+    // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id & 7), each with its own L2.  Every XCD gets a
+    // CONTIGUOUS range of M blocks (neighbouring pixel tiles share 3x3 halo rows) and walks the N blocks of one M block
+    // back to back, so the A tile an M block gathers is fetched into that XCD's L2 once and reused by all its N blocks
+    // (with N blocks on grid.y they ran a whole grid apart and A came back from MALL/HBM once per N block).
+    // The 1-D grid is padded to 8 * mpx * nnb ids; ids that fall outside the M range leave before any barrier.
+    const int orig = blockIdx.x, xcd = orig & 7, seq = orig >> 3;
+    const int nb = seq % a.nnb, ml = seq / a.nnb;
+    const int mb = xcd * a.mpx + ml;
+    if (mb >= a.nmb) return;
+    const int m0 = mb * BM, n0 = nb * BN;
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
     const T* zero = reinterpret_cast<const T*>(a.zero);
@@ -421,8 +423,12 @@ static TileChoice choose_tile(int64_t M, int64_t cout) {
 // instruction then touches 8 full 128-byte cache lines instead of 16 half lines, and there is one barrier per
 // 32 MFMAs per wave instead of per 16.  YMI_IGEMM_ROWB=64 forces the narrow form (tuning knob).
 template <typename T, bool STATS>
-static int launch_igemm_t(const IgemmArgs& a, TileChoice t, hipStream_t stream) {
-    dim3 grid((a.M + t.bm - 1) / t.bm, (a.Cout + t.bn - 1) / t.bn);
+static int launch_igemm_t(const IgemmArgs& a_in, TileChoice t, hipStream_t stream) {
+    IgemmArgs a = a_in;
+    a.nmb = (a.M + t.bm - 1) / t.bm;
+    a.nnb = (a.Cout + t.bn - 1) / t.bn;
+    a.mpx = (a.nmb + 7) / 8;
+    dim3 grid((unsigned)(8 * a.mpx * a.nnb));
     const bool fast = (a.cpt % 4) == 0;
     static const int rowb_env = getenv("YMI_IGEMM_ROWB") ? atoi(getenv("YMI_IGEMM_ROWB")) : 0;
     const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0 && rowb_env != 64;
