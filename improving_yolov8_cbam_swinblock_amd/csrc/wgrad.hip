@@ -29,6 +29,7 @@ struct WgradArgs {
     int stride, pad, KW;
     int CoutP, Cin, NG;
     int pix_per_split;
+    int nx, ny, splits, xcd_map;  // launch geometry (set by the launcher)
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -117,8 +118,22 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
-    const int j0 = blockIdx.x * WG_BN, co0 = blockIdx.y * WG_BM;
-    const int m_begin = blockIdx.z * a.pix_per_split;
+    // XCD-aware order (xcd_map): workgroup ids are dealt round-robin to the 8 XCDs; all tiles of one pixel split read the
+    // same dY / X rows (the nine taps are the same pixels, shifted), so a split's tiles are given to ONE XCD, back to
+    // back, and its rows are fetched into that L2 once.  Splits are dealt z = 8*i + xcd (balanced within one split).
+    int bx, by, bz;
+    if (a.xcd_map) {
+        const int id = blockIdx.x, xcd = id & 7, seq = id >> 3, nxy = a.nx * a.ny;
+        const int zi = seq / nxy, t = seq - zi * nxy;
+        bz = zi * 8 + xcd;
+        if (bz >= a.splits) return;  // padding ids leave before any barrier
+        by = t / a.nx;
+        bx = t - by * a.nx;
+    } else {
+        bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
+    }
+    const int j0 = bx * WG_BN, co0 = by * WG_BM;
+    const int m_begin = bz * a.pix_per_split;
     const int m_end = min(a.Mpix, m_begin + a.pix_per_split);
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ yg = reinterpret_cast<const T*>(a.dy);
@@ -199,7 +214,7 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
         WFrag<T>::template step<TR, TC>(Ys, Ys + YBYTES, wr * 32, wc * 64, lane, acc);
     }
 
-    float* slab = a.slab + (int64_t)blockIdx.z * a.CoutP * a.NG;
+    float* slab = a.slab + (int64_t)bz * a.CoutP * a.NG;
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int r = 0; r < TR; ++r)
@@ -283,6 +298,7 @@ static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng) {
     const int64_t smax = (mpix + 255) / 256;
     if (s > smax) s = smax;
     if (s < 1) s = 1;
+    if (s >= 8) s = (s + 7) / 8 * 8 <= smax ? (s + 7) / 8 * 8 : s / 8 * 8;  // splits are dealt to the 8 XCDs (see the kernel): keep them balanced
     int64_t pps = (mpix + s - 1) / s;
     pps = (pps + WG_BK - 1) / WG_BK * WG_BK;
     s = (mpix + pps - 1) / pps;
@@ -327,7 +343,11 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     a.Mpix = (int)mpix; a.H = (int)x->h; a.W = (int)x->w; a.Ho = (int)dy->h; a.Wo = (int)dy->w;
     a.stride = (int)stride; a.pad = (int)pad; a.KW = (int)kw;
     a.CoutP = (int)dy->c; a.Cin = (int)x->c; a.NG = (int)ng; a.pix_per_split = p.pix_per_split;
-    dim3 grid((unsigned)((ng + WG_BN - 1) / WG_BN), (unsigned)((dy->c + WG_BM - 1) / WG_BM), (unsigned)p.splits);
+    a.nx = (int)((ng + WG_BN - 1) / WG_BN); a.ny = (int)((dy->c + WG_BM - 1) / WG_BM); a.splits = p.splits;
+    static const int xcd_env = getenv("YMI_WGRAD_XCD") ? atoi(getenv("YMI_WGRAD_XCD")) : 1;  // tuning knob
+    a.xcd_map = (xcd_env && p.splits >= 8) ? 1 : 0;
+    dim3 grid((unsigned)a.nx, (unsigned)a.ny, (unsigned)p.splits);
+    if (a.xcd_map) grid = dim3((unsigned)(8 * ((p.splits + 7) / 8) * a.nx * a.ny), 1, 1);
     hipStream_t s = (hipStream_t)stream;
     int prof = -1;
     if (ymi_prof_enabled()) {
