@@ -294,7 +294,8 @@ struct WgradPlan {
 };
 static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng) {
     const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + WG_BM - 1) / WG_BM);
-    int64_t s = (1024 + tiles - 1) / tiles;
+    static const int target = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;  // workgroups to aim for (tuning knob)
+    int64_t s = (target + tiles - 1) / tiles;
     const int64_t smax = (mpix + 255) / 256;
     if (s > smax) s = smax;
     if (s < 1) s = 1;
