@@ -52,6 +52,13 @@ struct IgemmArgs {
     int nmb, nnb, mpx;                        // M blocks, N blocks, M blocks per XCD (launch geometry, set by the launcher)
 };
 
+// Up to four problems in one launch (the four output-parity classes of a stride-2 data gradient): consecutive ids of an
+// XCD walk the classes of one M block back to back, so the dY rows they all read enter that XCD's L2 once.
+struct IgemmMulti {
+    IgemmArgs c[4];
+    int ncls;
+};
+
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
@@ -111,7 +118,7 @@ template <> struct Mma<float> {
 
 
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int ROWB = CPR * 16;                    // bytes per LDS row = K step per row (64: 32 bf16 / 16 f32; 128: 64 bf16)
@@ -131,7 +138,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmArgs a) {
     // back to back, so the A tile an M block gathers is fetched into that XCD's L2 once and reused by all its N blocks
     // (with N blocks on grid.y they ran a whole grid apart and A came back from MALL/HBM once per N block).
     // The 1-D grid is padded to 8 * mpx * nnb ids; ids that fall outside the M range leave before any barrier.
-    const int orig = blockIdx.x, xcd = orig & 7, seq = orig >> 3;
+    const int orig = blockIdx.x, xcd = orig & 7, seq0 = orig >> 3;
+    const int cls = P.ncls > 1 ? seq0 % P.ncls : 0, seq = P.ncls > 1 ? seq0 / P.ncls : seq0;  // block-uniform
+    const IgemmArgs a = P.c[cls];
     const int nb = seq % a.nnb, ml = seq / a.nnb;
     const int mb = xcd * a.mpx + ml;
     if (mb >= a.nmb) return;
@@ -423,12 +432,19 @@ static TileChoice choose_tile(int64_t M, int64_t cout) {
 // instruction then touches 8 full 128-byte cache lines instead of 16 half lines, and there is one barrier per
 // 32 MFMAs per wave instead of per 16.  YMI_IGEMM_ROWB=64 forces the narrow form (tuning knob).
 template <typename T, bool STATS>
-static int launch_igemm_t(const IgemmArgs& a_in, TileChoice t, hipStream_t stream) {
-    IgemmArgs a = a_in;
-    a.nmb = (a.M + t.bm - 1) / t.bm;
-    a.nnb = (a.Cout + t.bn - 1) / t.bn;
-    a.mpx = (a.nmb + 7) / 8;
-    dim3 grid((unsigned)(8 * a.mpx * a.nnb));
+static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStream_t stream) {
+    IgemmMulti P{};
+    P.ncls = ncls;
+    int mpx = 0;
+    for (int i = 0; i < ncls; ++i) {
+        P.c[i] = arr[i];
+        P.c[i].nmb = (arr[i].M + t.bm - 1) / t.bm;
+        P.c[i].nnb = (arr[i].Cout + t.bn - 1) / t.bn;
+        if ((P.c[i].nmb + 7) / 8 > mpx) mpx = (P.c[i].nmb + 7) / 8;
+    }
+    for (int i = 0; i < ncls; ++i) P.c[i].mpx = mpx;  // one id decode for all classes (same Cout => same nnb)
+    const IgemmArgs& a = P.c[0];
+    dim3 grid((unsigned)(8 * mpx * a.nnb * ncls));
     const bool fast = (a.cpt % 4) == 0;
     static const int rowb_env = getenv("YMI_IGEMM_ROWB") ? atoi(getenv("YMI_IGEMM_ROWB")) : 0;
     const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0 && rowb_env != 64;
@@ -438,7 +454,7 @@ static int launch_igemm_t(const IgemmArgs& a_in, TileChoice t, hipStream_t strea
 #define YMI_LAUNCH1(KERNEL)                                                                                          \
     do {                                                                                                             \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(KERNEL, grid, dim3(256), lds, stream, a);                                                  \
+        hipLaunchKernelGGL(KERNEL, grid, dim3(256), lds, stream, P);                                                  \
     } while (0)
 #define YMI_LAUNCH(BM, BN, WM, WN)                                                              \
     do {                                                                                        \
@@ -467,21 +483,34 @@ bool ymi_prof_enabled();
 int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, double peak_tflops);
 void ymi_prof_stop(hipStream_t stream, int idx);
 
-int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
-    TileChoice t = choose_tile(a.M, a.Cout);
-    if (host_blocks) *host_blocks = (a.M + t.bm - 1) / t.bm;
+// ncls problems (same dtype, Cout, channel geometry) in one launch; statistics mode only for a single problem
+static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
+    int64_t mmax = 0;
+    for (int i = 0; i < ncls; ++i) mmax = arr[i].M > mmax ? arr[i].M : mmax;
+    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout);
+    if (host_blocks) *host_blocks = (arr[0].M + t.bm - 1) / t.bm;
     int prof = -1;
     if (ymi_prof_enabled()) {
         const double es = dtype == YMI_BF16 ? 2.0 : 4.0;
-        const double in_pix = (double)a.M / ((double)a.Ho * a.Wo) * (double)a.H * a.W;  // the whole input map, read once
-        const double bytes = in_pix * a.cpt * 16.0 + (double)a.ktot * a.Cout * es + (double)a.M * a.Cout * es * (a.res ? 2.0 : 1.0);
-        prof = ymi_prof_start(stream, 0, 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot, bytes, dtype == YMI_BF16 ? 2500.0 : 157.3);
+        double flop = 0.0, bytes = 0.0;
+        for (int i = 0; i < ncls; ++i) {
+            const IgemmArgs& a = arr[i];
+            flop += 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot;
+            bytes += (double)a.ktot * a.Cout * es + (double)a.M * a.Cout * es * (a.res ? 2.0 : 1.0);
+        }
+        const IgemmArgs& a0 = arr[0];
+        bytes += (double)a0.M / ((double)a0.Ho * a0.Wo) * (double)a0.H * a0.W * a0.cpt * 16.0;  // the whole input map, read once
+        prof = ymi_prof_start(stream, 0, flop, bytes, dtype == YMI_BF16 ? 2500.0 : 157.3);
     }
     int rc;
-    if (dtype == YMI_BF16) rc = stats ? launch_igemm_t<bf16_t, true>(a, t, stream) : launch_igemm_t<bf16_t, false>(a, t, stream);
-    else rc = stats ? launch_igemm_t<float, true>(a, t, stream) : launch_igemm_t<float, false>(a, t, stream);
+    if (dtype == YMI_BF16) rc = stats ? launch_igemm_t<bf16_t, true>(arr, ncls, t, stream) : launch_igemm_t<bf16_t, false>(arr, ncls, t, stream);
+    else rc = stats ? launch_igemm_t<float, true>(arr, ncls, t, stream) : launch_igemm_t<float, false>(arr, ncls, t, stream);
     ymi_prof_stop(stream, prof);
     return rc;
+}
+
+int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
+    return launch_igemm_n(&a, 1, dtype, stats, host_blocks, stream);
 }
 
 static void find_divisor(int d, uint32_t* mul, uint32_t* shr) {
@@ -577,6 +606,8 @@ extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_pac
     const char* wbase = reinterpret_cast<const char*>(w_dgrad_packed);
     int64_t woff = 0;  // elements
     const int nclass = stride == 1 ? 1 : 4;
+    IgemmArgs classes[4];
+    int nlaunch = 0;
     for (int cls = 0; cls < nclass; ++cls) {
         const int ph = stride == 1 ? 0 : cls / 2, pw = stride == 1 ? 0 : cls % 2;
         int dh[9], dw[9], nt = 0;
@@ -598,13 +629,19 @@ extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_pac
             a.act = YMI_ACT_NONE;
             a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0);
             finish_args(a, dx, nullptr);
-            int rc = ymi_launch_igemm(a, dy->dtype, false, nullptr, (hipStream_t)stream);
-            if (rc) return rc;
+            classes[nlaunch++] = a;
         } else if (ho > 0 && wo > 0) {
             ymi_set_error("conv2d_bwd_data: parity class without taps (k=1 stride=2 is not supported)");
             return YMI_EINVAL;
         }
         woff += (int64_t)nt * dy->c * cin;
+    }
+    static const int fuse_env = getenv("YMI_DGRAD_FUSE") ? atoi(getenv("YMI_DGRAD_FUSE")) : 1;  // 0: one launch per parity class
+    // (measured: fusing pays from 64 output channels up; the 32-channel layer 1 is 6 % faster class by class)
+    if (fuse_env && cin >= 64) return nlaunch ? launch_igemm_n(classes, nlaunch, dy->dtype, false, nullptr, (hipStream_t)stream) : YMI_OK;
+    for (int i = 0; i < nlaunch; ++i) {
+        int rc = ymi_launch_igemm(classes[i], dy->dtype, false, nullptr, (hipStream_t)stream);
+        if (rc) return rc;
     }
     return YMI_OK;
 }
