@@ -84,7 +84,10 @@ class TrainStep:
                 self.eager_step(self._static)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._graph):
+            # several ranks: the process group's watchdog thread polls its events while this thread captures; only
+            # this thread's calls may invalidate the capture
+            mode = "global" if self.world == 1 else "thread_local"
+            with torch.cuda.graph(self._graph, capture_error_mode=mode):
                 if self.full_graph:
                     self._static_items = self.eager_step(self._static)
                 else:

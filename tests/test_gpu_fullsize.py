@@ -14,7 +14,8 @@ def rel(a, b):
     return float((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm().clamp(min=1e-9))
 
 
-@pytest.mark.parametrize("cin,cout,k,s,hw", [(32, 64, 3, 2, 64), (64, 64, 3, 1, 40), (96, 64, 1, 1, 40), (256, 128, 1, 1, 20), (128, 256, 3, 2, 40)])
+@pytest.mark.parametrize("cin,cout,k,s,hw", [(32, 64, 3, 2, 64), (64, 64, 3, 1, 40), (96, 64, 1, 1, 40), (256, 128, 1, 1, 20), (128, 256, 3, 2, 40),
+                                             (64, 64, 3, 2, 21), (64, 128, 3, 2, 37)])  # odd sizes: the stride-2 parity classes differ in size
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_block_vs_oracle_midsize(cin, cout, k, s, hw, dtype):
     """multi-tile shapes (several M/N blocks, K loops over all taps) against the CPU oracle, fwd + all grads."""
@@ -36,7 +37,8 @@ def test_conv_block_vs_oracle_midsize(cin, cout, k, s, hw, dtype):
     m = m.to(dev()).train()
     o.train()
     x = torch.randn(4, cin, hw, hw)
-    gy = torch.randn(4, cout, hw // s, hw // s)
+    ho = (hw + 2 * (k // 2) - k) // s + 1
+    gy = torch.randn(4, cout, ho, ho)
     xo = x.clone().requires_grad_(True)
     yo = o(xo)
     go = torch.autograd.grad(yo, [xo] + list(o.parameters()), gy)
