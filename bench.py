@@ -181,7 +181,9 @@ def main():
     value = args.gpus * args.batch * args.steps / dt
     if rank == 0:
         out = {
-            "metric": "images/sec fwd+bwd YOLOv8s-CBAM-Swin bs=32 640x640",
+            # BASELINE.json's metric on its configuration; other --model / --batch / --imgsz values are named as they are
+            "metric": (f"images/sec fwd+bwd YOLOv8s-CBAM-Swin bs={args.batch} {args.imgsz}x{args.imgsz}" if args.model == "yolov8s.yaml"
+                       else f"images/sec fwd+bwd {args.model} bs={args.batch} {args.imgsz}x{args.imgsz}"),
             "value": round(value, 2),
             "unit": "images/sec",
             "n_gpus": args.gpus,
