@@ -419,12 +419,34 @@ struct TileChoice {
     int bm, bn;
 };
 
-static TileChoice choose_tile(int64_t M, int64_t cout) {
+// Largest tile that still yields ~1.5 workgroups per CU (measured on the 40x40 / 20x20 layers of the model: 400 tiles of
+// 128x128 beat 800 of 64x128 by 25-30 %, and below that 128x64, then 64x64, win); short-K GEMMs without the statistics
+// epilogue and many output channels are epilogue-dominated and run best as 128x64 (three resident workgroups per CU).
+static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats) {
     TileChoice t;
-    t.bn = cout <= 32 ? 32 : (cout <= 64 ? 64 : 128);
-    t.bm = 128;
-    const int64_t blocks = ((M + 127) / 128) * ((cout + t.bn - 1) / t.bn);
-    if (blocks < 512 && t.bn >= 64) t.bm = 64;
+    auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((cout + bn - 1) / bn); };
+    const int64_t enough = 400;
+    if (cout <= 32) {
+        t.bm = 128; t.bn = 32;
+    } else if (cout <= 64) {
+        t.bn = 64;
+        t.bm = blocks(128, 64) >= enough ? 128 : 64;
+    } else if (blocks(128, 128) >= enough) {
+        t.bm = 128;
+        t.bn = (!stats && ktot <= 512 && cout >= 256) ? 64 : 128;
+    } else if (blocks(128, 64) >= enough) {
+        t.bm = 128; t.bn = 64;
+    } else {
+        t.bm = 64; t.bn = 64;
+    }
+    static const char* tile_env = getenv("YMI_IGEMM_TILE");  // "bm,bn": force a tile (tuning knob)
+    if (tile_env) {
+        int bm = 0, bn = 0;
+        if (sscanf(tile_env, "%d,%d", &bm, &bn) == 2 && (bn <= 32 ? cout <= 32 : true)) {
+            t.bm = bm;
+            t.bn = bn;
+        }
+    }
     return t;
 }
 
@@ -486,8 +508,12 @@ void ymi_prof_stop(hipStream_t stream, int idx);
 // ncls problems (same dtype, Cout, channel geometry) in one launch; statistics mode only for a single problem
 static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
     int64_t mmax = 0;
-    for (int i = 0; i < ncls; ++i) mmax = arr[i].M > mmax ? arr[i].M : mmax;
-    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout);
+    int64_t kmax = 0;
+    for (int i = 0; i < ncls; ++i) {
+        mmax = arr[i].M > mmax ? arr[i].M : mmax;
+        kmax = arr[i].ktot > kmax ? arr[i].ktot : kmax;
+    }
+    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout, kmax, stats);
     if (host_blocks) *host_blocks = (arr[0].M + t.bm - 1) / t.bm;
     int prof = -1;
     if (ymi_prof_enabled()) {
