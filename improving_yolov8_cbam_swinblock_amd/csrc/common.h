@@ -42,6 +42,10 @@ static inline size_t ymi_esize(int dtype) { return dtype == YMI_BF16 ? 2 : 4; }
 static inline bool ymi_same_shape(const ymi_tensor* a, const ymi_tensor* b) {
     return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c;
 }
+// grid sizing of the streaming BatchNorm kernels (tuning knobs YMI_EW_PPT / YMI_EW_CAP): pixels each thread should get so
+// that its per-channel coefficient loads amortise, and the workgroup cap
+int ew_ppt();
+int ew_cap();
 // a 16-byte block of zeros in device memory (source of out-of-bounds im2col taps)
 const void* ymi_zero_page();
 

@@ -462,9 +462,9 @@ static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const fl
     const int64_t P = ymi_pixels(raw);
     const int rows = 256 / groups;
     // every thread reloads its group's scale/shift: give it ~8 pixels when the tensor allows, but keep >= 256 blocks
-    int64_t gb = (P + (int64_t)rows * 8 - 1) / ((int64_t)rows * 8);
+    int64_t gb = (P + (int64_t)rows * ew_ppt() - 1) / ((int64_t)rows * ew_ppt());
     if (gb < 256) gb = (P + rows - 1) / rows < 256 ? (P + rows - 1) / rows : 256;
-    if (gb > 2048) gb = 2048;  // one resident round of 256-thread blocks on 256 CUs
+    if (gb > ew_cap()) gb = ew_cap();  // default 2048: one resident round of 256-thread blocks on 256 CUs
     dim3 g((unsigned)gb), b(256);
     if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
     else if (act == YMI_ACT_GELU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_GELU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);

@@ -348,12 +348,12 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     if (fixed) {
         // every thread reloads its group's coefficients: give it at least ~8 pixels when the tensor allows
         const int rows = 256 / groups;
-        gb = (P + (int64_t)rows * 8 - 1) / ((int64_t)rows * 8);
+        gb = (P + (int64_t)rows * ew_ppt() - 1) / ((int64_t)rows * ew_ppt());
         if (gb < 256) gb = (P + rows - 1) / rows < 256 ? (P + rows - 1) / rows : 256;
     } else {
         gb = (total + 255) / 256;
     }
-    if (gb > 2048) gb = 2048;
+    if (gb > ew_cap()) gb = ew_cap();
     RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
 #define YMI_BWD_APPLY(T, GG, F, A) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, GG, F, A>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, coef)
 #define YMI_BWD_APPLY_A(T, GG, F)                                          \

@@ -2,6 +2,8 @@
 #include <stdarg.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include "common.h"
 
 static thread_local char g_err[512] = "";
@@ -32,4 +34,13 @@ const void* ymi_zero_page() {
         cached_dev = dev;
     }
     return cached_ptr;
+}
+
+int ew_ppt() {
+    static const int v = getenv("YMI_EW_PPT") ? atoi(getenv("YMI_EW_PPT")) : 8;
+    return v > 0 ? v : 8;
+}
+int ew_cap() {
+    static const int v = getenv("YMI_EW_CAP") ? atoi(getenv("YMI_EW_CAP")) : 2048;
+    return v > 0 ? v : 2048;
 }
