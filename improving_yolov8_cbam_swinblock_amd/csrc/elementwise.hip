@@ -302,7 +302,22 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
     if (c < C) {
-        for (int b = slice; b < blocks; b += 32) {
+        // four independent chains per sum: the loads of a trip are all in flight before the first add
+        float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
+        int b = slice;
+        for (; b + 96 < blocks; b += 128) {
+            a0 += part[((int64_t)b * 2 + 0) * C + c];
+            a1 += part[((int64_t)b * 2 + 1) * C + c];
+            b0 += part[((int64_t)(b + 32) * 2 + 0) * C + c];
+            b1 += part[((int64_t)(b + 32) * 2 + 1) * C + c];
+            c0 += part[((int64_t)(b + 64) * 2 + 0) * C + c];
+            c1 += part[((int64_t)(b + 64) * 2 + 1) * C + c];
+            d0 += part[((int64_t)(b + 96) * 2 + 0) * C + c];
+            d1 += part[((int64_t)(b + 96) * 2 + 1) * C + c];
+        }
+        s1 = ((double)a0 + (double)b0) + ((double)c0 + (double)d0);
+        s2 = ((double)a1 + (double)b1) + ((double)c1 + (double)d1);
+        for (; b < blocks; b += 32) {
             s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
             s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
         }
@@ -344,11 +359,21 @@ __global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __re
     const int c = blockIdx.x * 64 + cl;
     const int g = blockIdx.y;
     double s1 = 0.0, s2 = 0.0;
-    if (c < C)
-        for (int b = g + R * slice; b < blocks; b += 4 * R) {
+    if (c < C) {
+        int b = g + R * slice;
+        for (; b + 12 * R < blocks; b += 16 * R) {  // four rows per trip in flight
+            const float x0 = part[((int64_t)b * 2 + 0) * C + c], y0 = part[((int64_t)b * 2 + 1) * C + c];
+            const float x1 = part[((int64_t)(b + 4 * R) * 2 + 0) * C + c], y1 = part[((int64_t)(b + 4 * R) * 2 + 1) * C + c];
+            const float x2 = part[((int64_t)(b + 8 * R) * 2 + 0) * C + c], y2 = part[((int64_t)(b + 8 * R) * 2 + 1) * C + c];
+            const float x3 = part[((int64_t)(b + 12 * R) * 2 + 0) * C + c], y3 = part[((int64_t)(b + 12 * R) * 2 + 1) * C + c];
+            s1 += ((double)x0 + (double)x1) + ((double)x2 + (double)x3);
+            s2 += ((double)y0 + (double)y1) + ((double)y2 + (double)y3);
+        }
+        for (; b < blocks; b += 4 * R) {
             s1 += (double)part[((int64_t)b * 2 + 0) * C + c];
             s2 += (double)part[((int64_t)b * 2 + 1) * C + c];
         }
+    }
     red[0][slice][cl] = s1;
     red[1][slice][cl] = s2;
     __syncthreads();
