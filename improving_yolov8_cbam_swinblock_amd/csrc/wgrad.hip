@@ -232,27 +232,33 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
 // Slab reduction, one launch, deterministic: a 1024-thread workgroup owns 32 consecutive outputs (one 128-byte
 // row piece of every slab) and 32 split lanes; lane j sums splits j, j+32, ... in order, then the 32 lane sums are
 // added in lane order.  dw[co][ci][kh][kw] = sum_s slab[s][co][tap*Cin + ci]  (scatter into OIHW).
+// SL split lanes per output element (8, 16 or 32, chosen so that a lane sums ~8 splits): 1024 / SL consecutive outputs
+// per 1024-thread workgroup, so the grid is one resident round instead of two or three (the kernel is pure latency).
+template <int SL>
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real,
                                                              int cin_real, int ntaps, float* __restrict__ dw) {
-    __shared__ float red[32][33];
-    const int ol = threadIdx.x & 31, lane = threadIdx.x >> 5;
-    const int64_t e = (int64_t)blockIdx.x * 32 + ol;  // element of the [CoutP][NG] slab
+    constexpr int OUTS = 1024 / SL;
+    __shared__ float red[SL][OUTS + 1];
+    const int ol = threadIdx.x % OUTS, lane = threadIdx.x / OUTS;
+    const int64_t e = (int64_t)blockIdx.x * OUTS + ol;  // element of the [CoutP][NG] slab
     const int64_t elems = (int64_t)CoutP * NG;
-    float s0 = 0.f, s1 = 0.f;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (e < elems) {
         int k = lane;
-        for (; k + 32 < splits; k += 64) {  // two independent chains in flight
+        for (; k + 3 * SL < splits; k += 4 * SL) {  // four independent chains in flight
             s0 += slab[(int64_t)k * elems + e];
-            s1 += slab[(int64_t)(k + 32) * elems + e];
+            s1 += slab[(int64_t)(k + SL) * elems + e];
+            s2 += slab[(int64_t)(k + 2 * SL) * elems + e];
+            s3 += slab[(int64_t)(k + 3 * SL) * elems + e];
         }
-        if (k < splits) s0 += slab[(int64_t)k * elems + e];
+        for (; k < splits; k += SL) s0 += slab[(int64_t)k * elems + e];
     }
-    red[lane][ol] = s0 + s1;
+    red[lane][ol] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (lane == 0 && e < elems) {
         float s = 0.f;
 #pragma unroll
-        for (int q = 0; q < 32; ++q) s += red[q][ol];
+        for (int q = 0; q < SL; ++q) s += red[q][ol];
         const uint32_t eu = (uint32_t)e;  // < 2^31
         const int co = (int)(eu / (uint32_t)NG), col = (int)(eu - (uint32_t)co * (uint32_t)NG);
         const int tap = (int)((uint32_t)col / (uint32_t)Cin), ci = col - tap * Cin;
@@ -375,8 +381,12 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     YMI_CHECK_LAUNCH("wgrad");
     const int64_t elems = (int64_t)a.CoutP * a.NG;
     if (p.splits > 32) {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((elems + 31) / 32)), dim3(1024), 0, s, (const float*)a.slab, p.splits, a.CoutP,
-                           a.NG, a.Cin, (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
+#define YMI_WRED(SL) hipLaunchKernelGGL(wgrad_reduce_kernel<SL>, dim3((unsigned)((elems + 1024 / SL - 1) / (1024 / SL))), dim3(1024), 0, s, (const float*)a.slab, \
+                                        p.splits, a.CoutP, a.NG, a.Cin, (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw)
+        if (p.splits <= 64) YMI_WRED(8);
+        else if (p.splits <= 128) YMI_WRED(16);
+        else YMI_WRED(32);
+#undef YMI_WRED
     } else {
         const int64_t total = cout_real * kh * kw * cin_real;
         int64_t gb = (total + 255) / 256;
