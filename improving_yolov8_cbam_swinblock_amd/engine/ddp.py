@@ -85,6 +85,10 @@ class GradientBuckets:
         """pack the bucket's gradients into its flat buffer (one multi-tensor copy) and start the all-reduce."""
         if grads is None:
             grads = [p.grad for p in self.buckets[bi]]
+        if grads and grads[0].is_cuda:
+            from .. import ops
+
+            ops.join_side_stream()  # weight gradients may still be in flight on the side stream (ops.async_wgrad)
         torch._foreach_copy_(self._views[bi], grads)
         self._work[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
 

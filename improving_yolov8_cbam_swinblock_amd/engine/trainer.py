@@ -1,10 +1,16 @@
 """Training step of the hot path (reference: ultralytics/engine/trainer.py:383-399,614-622,788-849 and
 models/yolo/detect/train.py:90-115), reduced to what the benchmark step needs: bf16 autocast forward,
 v8 detection loss, backward (+ RCCL gradient mean), gradient clip 10.0, SGD-nesterov step."""
+import os
+
 import torch
 import torch.nn as nn
 
+from .. import ops
 from .ddp import GradientBuckets
+
+# weight-gradient GEMMs on a second stream during backward (ops.async_wgrad); YMI_WGRAD_STREAM=0 keeps one stream
+ASYNC_WGRAD = os.environ.get("YMI_WGRAD_STREAM", "1") != "0"
 
 
 def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
@@ -109,7 +115,8 @@ class TrainStep:
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             loss, items = self.model(batch)
             total = loss.sum() * self.world
-        total.backward()
+        with ops.async_wgrad(ASYNC_WGRAD):  # joins the side stream on exit
+            total.backward()
         return items
 
     def _reduce_and_update(self, grads_of=None):

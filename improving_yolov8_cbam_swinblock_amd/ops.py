@@ -233,6 +233,61 @@ def _wgrad(x, dy, cout, cin, k, stride, want_bias):
     return dw, db
 
 
+# ---- weight gradients on a second stream ------------------------------------------------------------------------
+# Inside `async_wgrad()` (the training step's backward) every weight-gradient GEMM (+ its slab reduce) is enqueued on a
+# side stream that forks from the current one: it depends only on (x, dz), and nothing downstream needs dW before the
+# optimizer, while the data-gradient / BatchNorm chain of the next layers continues on the current stream.  The small
+# 20x20 / 40x40 layers leave CUs idle in their tails; two independent kernel chains fill them.  Captured in a HIP graph
+# this becomes a parallel branch.  The operands are kept alive until the join so the allocator cannot hand their memory
+# to the main stream while the side stream still reads them.
+_side_streams = {}
+_async = {"on": False, "pending": False, "keep": []}
+
+
+def _side_stream(dev):
+    s = _side_streams.get(dev.index)
+    if s is None:
+        s = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return s
+
+
+class async_wgrad:
+    def __init__(self, enabled=True):
+        self.enabled = enabled
+
+    def __enter__(self):
+        self.prev = _async["on"]
+        _async["on"] = bool(self.enabled)
+        return self
+
+    def __exit__(self, *exc):
+        join_side_stream()
+        _async["on"] = self.prev
+        return False
+
+
+def join_side_stream():
+    """make the current stream wait for the weight-gradient stream (no-op when nothing is pending)."""
+    if _async["pending"]:
+        cur = torch.cuda.current_stream()
+        cur.wait_stream(_side_stream(cur.device))
+        _async["pending"] = False
+        _async["keep"].clear()
+
+
+def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias):
+    if not _async["on"]:
+        return _wgrad(x, dy, cout, cin, k, stride, want_bias)
+    cur = torch.cuda.current_stream()
+    side = _side_stream(x.device)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        out = _wgrad(x, dy, cout, cin, k, stride, want_bias)
+    _async["keep"].append((x, dy))
+    _async["pending"] = True
+    return out
+
+
 def _dgrad(dy, weight4, k, stride, in_shape, dtype):
     """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight; zero-padded input channels get zero."""
     n, cp, h, w = in_shape
@@ -316,7 +371,7 @@ class _ConvBnAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _dgrad(draw, weight, k, stride, x.shape, dtype)
-        dw, _ = _wgrad(x, draw, o, cin, k, stride, False)
+        dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False)
         dres = dout if (has_res and ctx.needs_input_grad[10]) else None
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None
 
@@ -412,7 +467,7 @@ class _ConvAffineAct(torch.autograd.Function):
                 wd = pack_conv_dgrad(w4, ty.c, 1, dtype)
                 dx = torch.empty((x.shape[0], x.shape[1]), dtype=dtype, device=x.device)
                 check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), x.shape[1], 1, 1, 1, _byref(as_ymi(dx)), stream_ptr()), "conv2d_bwd_data")
-        dw, db = _wgrad(x, dy, o, cin, k, stride, has_bias)
+        dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias)
         dw = dw.view(weight.shape)
         dres = None
         if has_res and ctx.needs_input_grad[6]:
