@@ -287,7 +287,7 @@ def _product_crit(nc):
     return DetectionModel(cfg, ch=3, nc=nc).to(dev()).init_criterion()
 
 
-@pytest.mark.parametrize("nc", [1, 5], ids=["nc1", "nc5"])
+@pytest.mark.parametrize("nc", [1, 5, 80], ids=["nc1", "nc5", "nc80"])
 @pytest.mark.parametrize("nb", [0, 1, 7, 40], ids=["empty", "one", "seven", "crowded"])
 def test_hip_loss_vs_oracle_random_batches(nb, nc):
     """HIP loss (csrc/loss.hip) against the CPU oracle on random predictions: empty batch, images without labels,
