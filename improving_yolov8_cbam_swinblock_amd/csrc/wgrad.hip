@@ -30,7 +30,10 @@ struct WgradArgs {
     int CoutP, Cin, NG;
     int pix_per_split;
     int nx, ny, splits, xcd_map;  // launch geometry (set by the launcher)
+    uint32_t wo_mul, wo_shr, ho_mul, ho_shr;  // n / Wo, n / Ho by multiply-high (0 multiplier: divisor 1)
 };
+
+__device__ __forceinline__ int wg_fast_div(int n, uint32_t mul, uint32_t shr) { return mul ? (int)(__umulhi((uint32_t)n, mul) >> shr) : n; }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -67,15 +70,15 @@ template <> struct WFrag<bf16_t> {
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
-    template <int TR, int TC>
+    template <int BM, int TR, int TC>
     static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 32; ++ks) {  // pixel rows 32*ks .. 32*ks+31 (the swizzles use row bits 0..3 only)
-            const char* Yk = Ys + ks * 32 * WG_BM * 2;
+            const char* Yk = Ys + ks * 32 * BM * 2;
             const char* Xk = Xs + ks * 32 * WG_BN * 2;
             bf16x8 af[TR], bfr[TC];
 #pragma unroll
-            for (int t = 0; t < TR; ++t) af[t] = load<false>(Yk, WG_BM * 2, r0 + t * 16, lane);
+            for (int t = 0; t < TR; ++t) af[t] = load<(BM == 128)>(Yk, BM * 2, r0 + t * 16, lane);  // 256-byte dY rows use the X swizzle
 #pragma unroll
             for (int t = 0; t < TC; ++t) bfr[t] = load<true>(Xk, WG_BN * 2, c0 + t * 16, lane);
 #pragma unroll
@@ -86,14 +89,14 @@ template <> struct WFrag<bf16_t> {
     }
 };
 template <> struct WFrag<float> {
-    template <int TR, int TC>
+    template <int BM, int TR, int TC>
     static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
         const int kq = lane >> 4, i = lane & 15;
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 4; ++ks) {
             float af[TR], bfr[TC];
 #pragma unroll
-            for (int t = 0; t < TR; ++t) af[t] = *reinterpret_cast<const float*>(Ys + ((4 * ks + kq) * WG_BM + r0 + t * 16 + i) * 4);
+            for (int t = 0; t < TR; ++t) af[t] = *reinterpret_cast<const float*>(Ys + ((4 * ks + kq) * BM + r0 + t * 16 + i) * 4);
 #pragma unroll
             for (int t = 0; t < TC; ++t) bfr[t] = *reinterpret_cast<const float*>(Xs + ((4 * ks + kq) * WG_BN + c0 + t * 16 + i) * 4);
 #pragma unroll
@@ -104,13 +107,15 @@ template <> struct WFrag<float> {
     }
 };
 
-template <typename T, int NS>
-__global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a) {
+// BM = output channels per workgroup tile: 64, or 128 for layers with >= 128 output channels (16 instead of 8 MFMAs per
+// wave and K step against the same address arithmetic: the K loop is instruction-issue-bound, not MFMA-bound)
+template <typename T, int NS, int BM>
+__global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
-    constexpr int YCW = WG_BM * ES / 16, XCW = WG_BN * ES / 16;        // 16-byte chunks per tile row
+    constexpr int YCW = BM * ES / 16, XCW = WG_BN * ES / 16;        // 16-byte chunks per tile row
     constexpr int NY = WG_BK * YCW / 256, NX = WG_BK * XCW / 256;     // chunks per thread per K step
-    constexpr int YBYTES = WG_BK * WG_BM * ES, XBYTES = WG_BK * WG_BN * ES;
+    constexpr int YBYTES = WG_BK * BM * ES, XBYTES = WG_BK * WG_BN * ES;
     constexpr int STAGE = YBYTES + XBYTES;
     static_assert(NY >= 1 && NX >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
     } else {
         bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
     }
-    const int j0 = bx * WG_BN, co0 = by * WG_BM;
+    const int j0 = bx * WG_BN, co0 = by * BM;
     const int m_begin = bz * a.pix_per_split;
     const int m_end = min(a.Mpix, m_begin + a.pix_per_split);
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
@@ -142,7 +147,7 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
     // dY loader: thread -> (row, chunk) ; chunk column fixed per thread.  bf16: LDS position (row, chunk') holds
     // source chunk chunk' ^ (swizzle(row) << 1); the row bits the swizzle uses are the same for all of a thread's rows.
     constexpr bool SWZ = std::is_same<T, bf16_t>::value;
-    const int ycc = SWZ ? ((tid % YCW) ^ (wg_swz_y(tid / YCW) << 1)) : (tid % YCW);
+    const int ycc = SWZ ? ((tid % YCW) ^ ((BM == 128 ? wg_swz_x(tid / YCW) : wg_swz_y(tid / YCW)) << 1)) : (tid % YCW);
     const bool y_cok = co0 + ycc * CH < a.CoutP;
     // X loader: column chunk fixed per thread -> fixed tap / input-channel offset
     const int xcc = SWZ ? ((tid % XCW) ^ (wg_swz_x(tid / XCW) << 1)) : (tid % XCW);
@@ -151,17 +156,7 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
     const int tap = x_cok ? j / a.Cin : 0;
     const int ci = x_cok ? j - tap * a.Cin : 0;
     const int dh = tap / a.KW - a.pad, dw = tap % a.KW - a.pad;
-    int xn[NX], xh[NX], xw[NX];
-#pragma unroll
-    for (int i = 0; i < NX; ++i) {
-        const int row = tid / XCW + i * (256 / XCW);
-        const int m = m_begin + row;
-        xw[i] = m % a.Wo;
-        const int t = m / a.Wo;
-        xh[i] = t % a.Ho;
-        xn[i] = t / a.Ho;
-    }
-
+    const int ldx32 = (int)a.ldx, ldy32 = (int)a.ldy;
     auto issue = [&](int s, int mk) {
         char* Ys = smem + s * STAGE;
         char* Xs = Ys + YBYTES;
@@ -170,30 +165,28 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
             const int row = tid / YCW + i * (256 / YCW);
             const int m = mk + row;
             const bool ok = y_cok && m < m_end;
-            const T* src = ok ? yg + (int64_t)m * a.ldy + co0 + ycc * CH : zero;
+            const T* src = ok ? yg + (uint32_t)(m * ldy32 + co0 + ycc * CH) : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * 256 + wave * 64) * 16), 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
+            // pixel -> (n, ho, wo) by two multiply-highs and 32-bit offsets (the host guarantees pixels * ld < 2^31): the
+            // address arithmetic of a K step must stay well below its 8 MFMAs' issue time
             const int row = tid / XCW + i * (256 / XCW);
             const int m = mk + row;
-            const int hi = xh[i] * a.stride + dh, wi = xw[i] * a.stride + dw;
+            const int t = wg_fast_div(m, a.wo_mul, a.wo_shr);
+            const int wo = m - t * a.Wo;
+            const int n = wg_fast_div(t, a.ho_mul, a.ho_shr);
+            const int ho = t - n * a.Ho;
+            const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;
             const bool ok = x_cok && m < m_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const T* src = ok ? xg + ((int64_t)(xn[i] * a.H + hi) * a.W + wi) * a.ldx + ci : zero;
+            const uint32_t off = (uint32_t)(((n * a.H + hi) * a.W + wi) * ldx32 + ci);
+            const T* src = ok ? xg + off : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * 256 + wave * 64) * 16), 16, 0, 0);
-            // advance this row's pixel by one K step
-            xw[i] += WG_BK;
-            while (xw[i] >= a.Wo) {
-                xw[i] -= a.Wo;
-                if (++xh[i] >= a.Ho) {
-                    xh[i] = 0;
-                    ++xn[i];
-                }
-            }
         }
     };
 
-    constexpr int TR = 2, TC = 4;  // per wave: 32 rows x 64 cols
+    constexpr int TR = BM / 32, TC = 4;  // per wave: BM/2 rows x 64 cols
     f32x4 acc[TR][TC];
 #pragma unroll
     for (int r = 0; r < TR; ++r)
@@ -211,7 +204,7 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
         else wait_vmcnt_barrier<0>();
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, m_begin + (kt + NS - 1) * WG_BK);
         const char* Ys = smem + (kt % NS) * STAGE;
-        WFrag<T>::template step<TR, TC>(Ys, Ys + YBYTES, wr * 32, wc * 64, lane, acc);
+        WFrag<T>::template step<BM, TR, TC>(Ys, Ys + YBYTES, wr * (BM / 2), wc * 64, lane, acc);
     }
 
     float* slab = a.slab + (int64_t)bz * a.CoutP * a.NG;
@@ -223,7 +216,7 @@ __global__ __launch_bounds__(256, YMI_WGRAD_WAVES) void wgrad_kernel(WgradArgs a
             const int col = j0 + wc * 64 + c * 16 + l15;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int co = co0 + wr * 32 + r * 16 + 4 * l4 + e;
+                const int co = co0 + wr * (BM / 2) + r * 16 + 4 * l4 + e;
                 if (co < a.CoutP && col < a.NG) slab[(int64_t)co * a.NG + col] = acc[r][c][e];
             }
         }
@@ -294,12 +287,30 @@ __global__ void wgrad_reduce_small_kernel(const float* __restrict__ slab, int sp
 
 constexpr int WG_STAGE_R = 0;
 
+// magic numbers for n / d by multiply-high, n < 2^31 (same construction as igemm.hip)
+static void wg_find_divisor(int d, uint32_t* mul, uint32_t* shr) {
+    if (d <= 1) { *mul = 0; *shr = 0; return; }
+    int lg = 0;
+    while ((1 << lg) < d) ++lg;
+    const int p = 31 + lg;
+    *mul = (uint32_t)(((1ull << p) + (uint64_t)d - 1) / (uint64_t)d);
+    *shr = (uint32_t)(p - 32);
+}
+
 struct WgradPlan {
     int splits, pix_per_split;
     size_t slab_bytes;
 };
-static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng) {
-    const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + WG_BM - 1) / WG_BM);
+// row-tile choice.  Measured: the 128-row tile is 5-45 % SLOWER on every conv layer with >= 128 output channels (the
+// pixel axis is split twice as often for the same workgroup count, doubling the slab traffic) and ~6 % faster only on
+// the two widest token GEMMs, so 64 stays the default; YMI_WGRAD_BM=128 selects it where the layer allows.
+static int wgrad_bm(int64_t coutp, bool bf16) {
+    static const int env = getenv("YMI_WGRAD_BM") ? atoi(getenv("YMI_WGRAD_BM")) : 64;
+    if (!bf16 || env != 128) return 64;
+    return (coutp >= 128 && coutp % 128 == 0) || coutp >= 256 ? 128 : 64;
+}
+static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm = WG_BM) {
+    const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + bm - 1) / bm);
     static const int target = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;  // workgroups to aim for (tuning knob)
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t smax = (mpix + 255) / 256;
@@ -321,7 +332,9 @@ static int64_t pad_to(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 extern "C" size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, int64_t cin, int64_t kh, int64_t kw) {
     // upper bound over both dtypes' channel padding (8), plus room for the bias-gradient partials
     const int64_t coutp = pad_to(cout, 8), cinp = pad_to(cin, 8);
-    WgradPlan p = wgrad_plan(m_rows, coutp, kh * kw * cinp);
+    WgradPlan p = wgrad_plan(m_rows, coutp, kh * kw * cinp, 64);
+    const WgradPlan p128 = wgrad_plan(m_rows, coutp, kh * kw * cinp, 128);  // the 128-row tile splits the pixel axis further
+    if (p128.slab_bytes > p.slab_bytes) p = p128;
     return p.slab_bytes + (size_t)(2048 * 2 + 1) * coutp * sizeof(float) + 256;
 }
 
@@ -338,7 +351,8 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     YMI_CHECK_ARG(ymi_pixels(x) * x->ld < (1ll << 31) && ymi_pixels(dy) * dy->ld < (1ll << 31), "conv2d_bwd_weight: too large");
     const int64_t mpix = ymi_pixels(dy);
     const int64_t ng = kh * kw * x->c;
-    WgradPlan p = wgrad_plan(mpix, dy->c, ng);
+    const int bm = wgrad_bm(dy->c, x->dtype == YMI_BF16);
+    WgradPlan p = wgrad_plan(mpix, dy->c, ng, bm);
     size_t need = p.slab_bytes + (dbias ? (size_t)(2048 * 2 + 1) * dy->c * sizeof(float) : 0);
     if (workspace_bytes < need) {
         ymi_set_error("conv2d_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -350,7 +364,9 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     a.Mpix = (int)mpix; a.H = (int)x->h; a.W = (int)x->w; a.Ho = (int)dy->h; a.Wo = (int)dy->w;
     a.stride = (int)stride; a.pad = (int)pad; a.KW = (int)kw;
     a.CoutP = (int)dy->c; a.Cin = (int)x->c; a.NG = (int)ng; a.pix_per_split = p.pix_per_split;
-    a.nx = (int)((ng + WG_BN - 1) / WG_BN); a.ny = (int)((dy->c + WG_BM - 1) / WG_BM); a.splits = p.splits;
+    wg_find_divisor(a.Wo, &a.wo_mul, &a.wo_shr);
+    wg_find_divisor(a.Ho, &a.ho_mul, &a.ho_shr);
+    a.nx = (int)((ng + WG_BN - 1) / WG_BN); a.ny = (int)((dy->c + bm - 1) / bm); a.splits = p.splits;
     static const int xcd_env = getenv("YMI_WGRAD_XCD") ? atoi(getenv("YMI_WGRAD_XCD")) : 1;  // tuning knob
     a.xcd_map = (xcd_env && p.splits >= 8) ? 1 : 0;
     dim3 grid((unsigned)a.nx, (unsigned)a.ny, (unsigned)p.splits);
@@ -364,18 +380,22 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     }
     if (x->dtype == YMI_BF16) {
         static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
-        const size_t lds = (size_t)ns * (size_t)(WG_BK * (WG_BM + WG_BN) * 2);
-        if (ns > 2) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        const size_t lds = (size_t)ns * (size_t)(WG_BK * (bm + WG_BN) * 2);
+        if (bm == 128) {
+            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2), s, a);
+        } else {
+            if (ns > 2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            }
+            if (ns == 4) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 4, 64>), grid, dim3(256), lds, s, a);
+            else if (ns == 3) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3, 64>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 64>), grid, dim3(256), lds, s, a);
         }
-        if (ns == 4) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 4>), grid, dim3(256), lds, s, a);
-        else if (ns == 3) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2>), grid, dim3(256), lds, s, a);
     } else {
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((wgrad_kernel<float, 2>), grid, dim3(256), lds, s, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((wgrad_kernel<float, 2, 64>), grid, dim3(256), lds, s, a);
     }
     ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");
