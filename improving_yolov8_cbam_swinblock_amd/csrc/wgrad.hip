@@ -30,10 +30,12 @@ struct WgradArgs {
     int CoutP, Cin, NG;
     int pix_per_split;
     int nx, ny, splits, xcd_map;  // launch geometry (set by the launcher)
-    uint32_t wo_mul, wo_shr, ho_mul, ho_shr;  // n / Wo, n / Ho by multiply-high (0 multiplier: divisor 1)
+    uint32_t wo_mul, wo_shr, ho_mul, ho_shr;  // n / Wo, n / Ho by multiply-high (wg_fast_div)
 };
 
-__device__ __forceinline__ int wg_fast_div(int n, uint32_t mul, uint32_t shr) { return mul ? (int)(__umulhi((uint32_t)n, mul) >> shr) : n; }
+// n / d for 0 <= n < 2^31 as (umulhi(n, mul) + n) >> shr with mul = floor(2^32 (2^shr - d) / d) + 1, shr = ceil(log2 d)
+// (Granlund-Montgomery; exact also for d = 1 and powers of two, so the K loop needs no special case and no branch)
+__device__ __forceinline__ int wg_fast_div(int n, uint32_t mul, uint32_t shr) { return (int)((__umulhi((uint32_t)n, mul) + (uint32_t)n) >> shr); }
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -287,14 +289,12 @@ __global__ void wgrad_reduce_small_kernel(const float* __restrict__ slab, int sp
 
 constexpr int WG_STAGE_R = 0;
 
-// magic numbers for n / d by multiply-high, n < 2^31 (same construction as igemm.hip)
+// magic numbers for wg_fast_div
 static void wg_find_divisor(int d, uint32_t* mul, uint32_t* shr) {
-    if (d <= 1) { *mul = 0; *shr = 0; return; }
     int lg = 0;
     while ((1 << lg) < d) ++lg;
-    const int p = 31 + lg;
-    *mul = (uint32_t)(((1ull << p) + (uint64_t)d - 1) / (uint64_t)d);
-    *shr = (uint32_t)(p - 32);
+    *mul = (uint32_t)((((uint64_t)1 << 32) * (((uint64_t)1 << lg) - (uint64_t)d)) / (uint64_t)d + 1);
+    *shr = (uint32_t)lg;
 }
 
 struct WgradPlan {
