@@ -9,7 +9,9 @@ import torch.nn as nn
 from .. import ops
 from .ddp import GradientBuckets
 
-# weight-gradient GEMMs on a second stream during backward (ops.async_wgrad); YMI_WGRAD_STREAM=0 keeps one stream
+# weight-gradient GEMMs on a second stream during backward (ops.async_wgrad) in EAGER steps; YMI_WGRAD_STREAM=0 keeps
+# one stream.  Graph-replayed steps stay single-stream: measured no wall-time gain there, and concurrent kernels stretch
+# each other's durations, which would blur the per-kernel roofline measurement.
 ASYNC_WGRAD = os.environ.get("YMI_WGRAD_STREAM", "1") != "0"
 
 
@@ -115,7 +117,7 @@ class TrainStep:
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             loss, items = self.model(batch)
             total = loss.sum() * self.world
-        with ops.async_wgrad(ASYNC_WGRAD):  # joins the side stream on exit
+        with ops.async_wgrad(ASYNC_WGRAD and not self.use_graph):  # joins the side stream on exit
             total.backward()
         return items
 
