@@ -30,7 +30,9 @@ def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
                 g_n.append(p)
             else:
                 g_w.append(p)
-    opt = torch.optim.SGD(g_b, lr=lr, momentum=momentum, nesterov=True)
+    # fused multi-tensor update on the GPU (one kernel per parameter group instead of a chain of foreach passes)
+    fused = bool(g_b) and g_b[0].is_cuda and os.environ.get("YMI_FUSED_SGD", "1") != "0"
+    opt = torch.optim.SGD(g_b, lr=lr, momentum=momentum, nesterov=True, fused=True if fused else None)  # None: foreach
     opt.add_param_group({"params": g_w, "weight_decay": decay})
     opt.add_param_group({"params": g_n, "weight_decay": 0.0})
     return opt
