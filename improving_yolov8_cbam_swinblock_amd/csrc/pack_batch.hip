@@ -10,6 +10,10 @@ struct PackDesc {  // mirrors ymi_pack_desc
     int32_t o, i, kh, kw, ipad, opad, stride, pad_;
 };
 
+// One thread per (output channel, padded input channel) pair for the forward operand and per (input channel, padded
+// output channel) pair for the data-gradient operand; the thread walks the kh*kw taps, which lie CONTIGUOUSLY in the
+// OIHW source (one 36-byte run for a 3x3 kernel), so every source byte is fetched once, and for a fixed tap
+// consecutive lanes write consecutive destination elements.  A tensor owns ceil(max(O*ipad, I*opad) / 256) workgroups.
 template <typename T>
 __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restrict__ descs, const int32_t* __restrict__ block_start, int count) {
     // binary search: tensor t with block_start[t] <= blockIdx.x < block_start[t+1]
@@ -20,53 +24,36 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
         else hi = mid;
     }
     const PackDesc d = descs[lo];
-    // 32-bit index arithmetic throughout (the host checks every operand has < 2^31 elements): 64-bit integer
-    // division costs an order of magnitude more instructions and this kernel is nothing but index arithmetic
-    const uint32_t base = (uint32_t)((int)blockIdx.x - block_start[lo]) * 1024u;
-    const uint32_t taps = (uint32_t)(d.kh * d.kw);
-    const uint32_t nfwd = d.dst_fwd ? (uint32_t)d.o * taps * (uint32_t)d.ipad : 0u;
-    const uint32_t ndg = d.dst_dgrad ? (uint32_t)d.i * taps * (uint32_t)d.opad : 0u;
-    const int pad = d.kh / 2;
-    const int smask = d.stride - 1;  // stride is 1 or 2: (v % stride == 0) <=> ((v & smask) == 0), without a division
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const uint32_t idx = base + u * 256 + threadIdx.x;
-        if (idx < nfwd) {  // dst[o][kh][kw][ip] <- src[o][i][kh][kw]
-            const uint32_t t = idx / (uint32_t)d.ipad;
-            const uint32_t ip = idx - t * (uint32_t)d.ipad;
-            const uint32_t o = t / taps;
-            const uint32_t tp = t - o * taps;
-            const float v = ip < (uint32_t)d.i ? d.src[(o * (uint32_t)d.i + ip) * taps + tp] : 0.0f;
-            reinterpret_cast<T*>(d.dst_fwd)[idx] = from_f32<T>(v);
-        }
-        if (idx < ndg) {  // class blocks back to back: dst[ci][t_in_class][op] <- src[o][ci][kh_t][kw_t]
-            uint32_t rem = idx;
-            const int nclass = d.stride == 1 ? 1 : 4;
-            for (int cls = 0; cls < nclass; ++cls) {
-                const int ph = d.stride == 1 ? 0 : cls >> 1, pw = d.stride == 1 ? 0 : cls & 1;
-                int nt = 0;
-                for (int a = 0; a < d.kh; ++a)
-                    for (int b = 0; b < d.kw; ++b)
-                        if (((ph + pad - a) & smask) == 0 && ((pw + pad - b) & smask) == 0) ++nt;
-                const uint32_t sz = (uint32_t)d.i * (uint32_t)nt * (uint32_t)d.opad;
-                if (rem < sz) {
-                    const uint32_t t = rem / (uint32_t)d.opad;
-                    const int o = (int)(rem - t * (uint32_t)d.opad);
-                    const uint32_t ci = t / (uint32_t)nt;
-                    const int tq = (int)(t - ci * (uint32_t)nt);
-                    int seen = 0, ka = 0, kb = 0;
-                    for (int a = 0; a < d.kh; ++a)
-                        for (int b = 0; b < d.kw; ++b)
-                            if (((ph + pad - a) & smask) == 0 && ((pw + pad - b) & smask) == 0) {
-                                if (seen == tq) { ka = a; kb = b; }
-                                ++seen;
-                            }
-                    const float v = o < d.o ? d.src[(((uint32_t)o * (uint32_t)d.i + ci) * (uint32_t)d.kh + (uint32_t)ka) * (uint32_t)d.kw + (uint32_t)kb] : 0.0f;
-                    reinterpret_cast<T*>(d.dst_dgrad)[idx] = from_f32<T>(v);
-                    break;
-                }
-                rem -= sz;
-            }
+    const uint32_t idx = (uint32_t)((int)blockIdx.x - block_start[lo]) * 256u + threadIdx.x;
+    const uint32_t taps = (uint32_t)(d.kh * d.kw), I = (uint32_t)d.i, O = (uint32_t)d.o;
+    if (d.dst_fwd && idx < O * (uint32_t)d.ipad) {  // dst[o][tap][ip] <- src[o][i][tap]
+        const uint32_t o = idx / (uint32_t)d.ipad, ip = idx - o * (uint32_t)d.ipad;
+        const float* src = d.src + ((uint64_t)o * I + ip) * taps;
+        T* dst = reinterpret_cast<T*>(d.dst_fwd) + (uint64_t)o * taps * d.ipad + ip;
+        for (uint32_t t = 0; t < taps; ++t) dst[(uint64_t)t * d.ipad] = from_f32<T>(ip < I ? src[t] : 0.0f);
+    }
+    if (d.dst_dgrad && idx < I * (uint32_t)d.opad) {  // class blocks back to back: dst[ci][tap in class][op] <- src[o][ci][kh][kw]
+        const uint32_t ci = idx / (uint32_t)d.opad, o = idx - ci * (uint32_t)d.opad;
+        const float* src = d.src + ((uint64_t)o * I + ci) * taps;
+        T* dst = reinterpret_cast<T*>(d.dst_dgrad);
+        const int pad = d.kh / 2, smask = d.stride - 1;  // stride 1 or 2: (v % stride == 0) <=> ((v & smask) == 0)
+        const int nclass = d.stride == 1 ? 1 : 4;
+        uint64_t class_off = 0;
+        for (int cls = 0; cls < nclass; ++cls) {
+            const int ph = d.stride == 1 ? 0 : cls >> 1, pw = d.stride == 1 ? 0 : cls & 1;
+            int nt = 0;
+            for (int a = 0; a < d.kh; ++a)
+                for (int b = 0; b < d.kw; ++b)
+                    if (((ph + pad - a) & smask) == 0 && ((pw + pad - b) & smask) == 0) ++nt;
+            int tq = 0;
+            for (int a = 0; a < d.kh; ++a)
+                for (int b = 0; b < d.kw; ++b)
+                    if (((ph + pad - a) & smask) == 0 && ((pw + pad - b) & smask) == 0) {
+                        const float v = o < O ? src[a * d.kw + b] : 0.0f;
+                        dst[class_off + ((uint64_t)ci * nt + tq) * d.opad + o] = from_f32<T>(v);
+                        ++tq;
+                    }
+            class_off += (uint64_t)I * nt * d.opad;
         }
     }
 }

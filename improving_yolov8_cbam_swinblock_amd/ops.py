@@ -158,7 +158,8 @@ class WeightArena:
             w = sp["weight"]
             descs[n] = _PackDesc(w.data_ptr(), base + offf * es if nf else None, base + offd * es if nd else None, sp["o"], sp["i"], sp["k"],
                                  sp["k"], sp["ipad"] or 0, sp["opad"] or 0, sp["stride"], 0)
-            starts.append(starts[-1] + (max(nf, nd) + 1023) // 1024)
+            pairs = max(sp["o"] * sp["ipad"] if nf else 0, sp["i"] * sp["opad"] if nd else 0)  # one thread per (channel, padded channel) pair
+            starts.append(starts[-1] + (pairs + 255) // 256)
             self.views[key] = (self.arena[offf : offf + nf] if nf else None, self.arena[offd : offd + nd] if nd else None, sp["ipad"], sp["opad"], sp["stride"])
         raw = bytes(descs)
         self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
