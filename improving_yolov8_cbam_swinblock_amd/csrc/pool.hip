@@ -174,6 +174,18 @@ struct PoolBwdArgs {
     int k, TH, TW;
 };
 
+// CN one-byte arg-max codes of a 16-byte channel chunk, packed: one 8-byte (bf16) / 4-byte (f32) LDS access
+template <int CN> __device__ __forceinline__ void store_codes(unsigned char* p, const int (&code)[CN]) {
+    uint64_t v = 0;
+#pragma unroll
+    for (int e = 0; e < CN; ++e) v |= (uint64_t)(code[e] & 255) << (8 * e);
+    if (CN == 8) *reinterpret_cast<uint64_t*>(p) = v;
+    else *reinterpret_cast<uint32_t*>(p) = (uint32_t)v;
+}
+template <int CN> __device__ __forceinline__ uint64_t load_codes(const unsigned char* p) {
+    return CN == 8 ? *reinterpret_cast<const uint64_t*>(p) : (uint64_t)*reinterpret_cast<const uint32_t*>(p);
+}
+
 // one stage: gin[s] += sum_{p in window(s)} [argmax(x, window(p)) == s] gout[p]
 // NCH = 16-byte channel chunks per pixel owned by one workgroup (4: a 64-byte slab, coalesced for large maps;
 // 1: four times as many workgroups, for the small SPPF maps where the launch would not fill the chip otherwise).
@@ -244,8 +256,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
                 }
         }
         Chunk<T>::store(RM + (size_t)i * 16, best);
-#pragma unroll
-        for (int e = 0; e < CN; ++e) RC[(size_t)px * CS + ch * CN + e] = (unsigned char)code[e];
+        store_codes<CN>(RC + (size_t)px * CS + ch * CN, code);
     }
     __syncthreads();
     // column pass: arg-max code (dy*k + dx) of every window centred in the G region
@@ -262,15 +273,15 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
             const size_t rp = (size_t)(hh - xh0) * GW + wl;
             float v[CN];
             Chunk<T>::load(RM + (rp * NCH + ch) * 16, v);
+            const uint64_t rc = load_codes<CN>(RC + rp * CS + ch * CN);
 #pragma unroll
             for (int e = 0; e < CN; ++e)
                 if (code[e] < 0 || v[e] > best[e]) {
                     best[e] = v[e];
-                    code[e] = dy * k + RC[rp * CS + ch * CN + e];
+                    code[e] = dy * k + (int)((rc >> (8 * e)) & 255);
                 }
         }
-#pragma unroll
-        for (int e = 0; e < CN; ++e) IDX[(size_t)px * CS + ch * CN + e] = (unsigned char)code[e];
+        store_codes<CN>(IDX + (size_t)px * CS + ch * CN, code);
     }
     __syncthreads();
     T* gi = reinterpret_cast<T*>(a.gin.p);
@@ -292,9 +303,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
                 const size_t gp = (size_t)(ph - gh0) * GW + (pw - gw0);
                 float g[CN];
                 Chunk<T>::load(G + (gp * NCH + ch) * 16, g);
+                const uint64_t ix = load_codes<CN>(IDX + gp * CS + ch * CN);  // one LDS access for the CN arg-max codes
 #pragma unroll
                 for (int e = 0; e < CN; ++e)
-                    if (IDX[gp * CS + ch * CN + e] == want) acc[e] += g[e];
+                    if ((int)((ix >> (8 * e)) & 255) == want) acc[e] += g[e];
             }
         }
         Chunk<T>::store(dst, acc);
