@@ -301,17 +301,19 @@ struct WgradPlan {
     int splits, pix_per_split;
     size_t slab_bytes;
 };
-// row-tile choice.  Measured: the 128-row tile is 5-45 % SLOWER on every conv layer with >= 128 output channels (the
-// pixel axis is split twice as often for the same workgroup count, doubling the slab traffic) and ~6 % faster only on
-// the two widest token GEMMs, so 64 stays the default; YMI_WGRAD_BM=128 selects it where the layer allows.
+// row-tile choice.  Measured: with the same workgroup target as the 64-row tile the 128-row tile is 5-45 % SLOWER (the
+// pixel axis is split twice as often, doubling the slab traffic); with HALF the workgroups (same split count, 16 MFMAs
+// per wave and K step) it is 7-12 % faster on every layer with >= 128 output channels.  YMI_WGRAD_BM=64 disables it.
 static int wgrad_bm(int64_t coutp, bool bf16) {
-    static const int env = getenv("YMI_WGRAD_BM") ? atoi(getenv("YMI_WGRAD_BM")) : 64;
+    static const int env = getenv("YMI_WGRAD_BM") ? atoi(getenv("YMI_WGRAD_BM")) : 128;
     if (!bf16 || env != 128) return 64;
     return (coutp >= 128 && coutp % 128 == 0) || coutp >= 256 ? 128 : 64;
 }
 static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm = WG_BM) {
     const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + bm - 1) / bm);
-    static const int target = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;  // workgroups to aim for (tuning knob)
+    static const int target64 = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;  // workgroups to aim for (tuning knobs)
+    static const int target128 = getenv("YMI_WGRAD_BLOCKS128") ? atoi(getenv("YMI_WGRAD_BLOCKS128")) : 640;
+    const int target = bm == 128 ? target128 : target64;
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t smax = (mpix + 255) / 256;
     if (s > smax) s = smax;
