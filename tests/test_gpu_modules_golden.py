@@ -332,3 +332,32 @@ def test_hip_loss_bf16_maps_and_max_boxes_hint():
         close_l2(x.grad, y.grad, 5e-3, "bf16 loss gradient")
     a2, _ = crit([p.clone().to(dev()) for p in preds], dbatch)
     torch.testing.assert_close(a2, a.detach(), rtol=1e-6, atol=1e-7)
+
+
+def test_weight_arena_pack_equals_per_call_pack():
+    """the one-launch batched pack (ymi_pack_conv_weights_batch) writes exactly the operands the per-layer pack
+    functions write: forward [O][tap][Ipad] and data-gradient [I][tap in class][Opad], stride 1 and 2, 1x1 and 3x3,
+    with channel padding on both sides."""
+    from improving_yolov8_cbam_swinblock_amd import ops
+
+    torch.manual_seed(3)
+    cases = [(24, 13, 3, 2, 16, 24), (64, 64, 3, 1, 64, 64), (40, 32, 1, 1, 32, 40), (7, 8, 3, 2, 8, 8)]  # (o, i, k, stride, ipad, opad)
+    for dt in (torch.bfloat16, torch.float32):
+        arena = ops.WeightArena()
+        ops.set_weight_arena(arena)
+        try:
+            ws, ref = [], []
+            for o, i, k, s, ipad, opad in cases:
+                w = torch.randn(o, i, k, k, device=dev())
+                ws.append(w)
+                ref.append((ops.pack_conv_fwd(w, ipad, dt).clone(), ops.pack_conv_dgrad(w, opad, s, dt).clone()))  # recorded + per-call pack
+            arena.build()
+            arena.pack()
+            for w, (o, i, k, s, ipad, opad), (rf, rd) in zip(ws, cases, ref):
+                f = arena.lookup_fwd(w, ipad, dt)
+                d = arena.lookup_dgrad(w, opad, s, dt)
+                assert f is not None and d is not None
+                assert torch.equal(f, rf), ("fwd", o, i, k, s)
+                assert torch.equal(d, rd), ("dgrad", o, i, k, s)
+        finally:
+            ops.set_weight_arena(None)
