@@ -108,10 +108,21 @@ extern "C" int ymi_window_reverse(const ymi_tensor* tokens, int64_t ws, const ym
 }
 
 // -------------------------------------------------------------------------------- LayerNorm
-constexpr int LN_MAXG = 4;  // C <= 64 lanes * 4 * LN_MAXG = 1024
+// C <= 64 lanes * 4 channels * 4 groups = 1024
+// the kernels are instantiated per number of ACTIVE 256-channel groups (C = 256 -> 1): the per-token loop is a serial
+// load -> reduce -> store chain hidden only by resident waves, and register arrays sized for 1024 channels cut those
+#define YMI_LN_G(LAUNCH, T)                     \
+    do {                                        \
+        const int g_ = ((int)x->c + 255) / 256; \
+        if (g_ <= 1) LAUNCH(T, 1);              \
+        else if (g_ == 2) LAUNCH(T, 2);         \
+        else if (g_ == 3) LAUNCH(T, 3);         \
+        else LAUNCH(T, 4);                      \
+    } while (0)
+#define YMI_LNF(T, G) hipLaunchKernelGGL((layernorm_fwd_kernel<T, G>), grid, dim3(256), 0, (hipStream_t)stream, xv, ov, T_, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, beta, eps, mean, rstd)
 
 // one wave per token; ws > 0: rows are gathered from the NHWC image through the window map
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(SV x, SV out, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C,
                                                             const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
                                                             float* __restrict__ mean, float* __restrict__ rstd) {
@@ -122,10 +133,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(SV x, SV out, int64_
     int64_t row = t;
     if (ws > 0) row = token_pixel(t, H, W, Hp, Wp, ws, &real);
     const T* xp = reinterpret_cast<const T*>(x.p) + row * x.ld;
-    float v[LN_MAXG][4];
+    float v[G][4];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXG; ++i) {
+    for (int i = 0; i < G; ++i) {
         const int c = lane * 4 + 256 * i;
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[i][r] = 0.f;
@@ -136,7 +147,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(SV x, SV out, int64_
     const float mu = wave_sum(s) / (float)C;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXG; ++i) {
+    for (int i = 0; i < G; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < C)
 #pragma unroll
@@ -145,7 +156,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(SV x, SV out, int64_
     const float rs = rsqrtf(wave_sum(q) / (float)C + eps);
     T* op = reinterpret_cast<T*>(const_cast<void*>(out.p)) + t * out.ld;
 #pragma unroll
-    for (int i = 0; i < LN_MAXG; ++i) {
+    for (int i = 0; i < G; ++i) {
         const int c = lane * 4 + 256 * i;
         if (c < C) {
             float o[4];
@@ -167,29 +178,30 @@ extern "C" int ymi_layernorm_fwd(const ymi_tensor* x, int64_t ws, const float* g
     int64_t Hp = x->h, Wp = x->w;
     if (ws > 0) window_geometry(x, ws, &Hp, &Wp);
     const int64_t T = ws > 0 ? x->n * Hp * Wp : ymi_pixels(x);
+    const int64_t T_ = T;  // (name used by the launch macros)
     YMI_CHECK_ARG(ymi_pixels(out) == T, "layernorm_fwd: output must hold %lld tokens", (long long)T);
     SV xv{x->data, x->ld}, ov{out->data, out->ld};
     dim3 grid((unsigned)((T + 3) / 4));
     if (x->dtype == YMI_BF16)
-        hipLaunchKernelGGL(layernorm_fwd_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, xv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, beta, eps, mean, rstd);
+        YMI_LN_G(YMI_LNF, bf16_t);
     else
-        hipLaunchKernelGGL(layernorm_fwd_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, xv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, beta, eps, mean, rstd);
+        YMI_LN_G(YMI_LNF, float);
     YMI_CHECK_LAUNCH("layernorm_fwd");
     return YMI_OK;
 }
 
 // backward: dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); per-block partials of dgamma/dbeta.
 // ACCUM: dx += (used when the LayerNorm input also feeds a residual branch).
-template <typename T>
+template <typename T, int G>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, float* __restrict__ part, int accumulate) {
     extern __shared__ float red_dyn[];  // [4 waves][2][Cr], Cr = C rounded up to 256: sized by the launcher, so 8+ workgroups fit a CU
     const int Cr = (C + 255) / 256 * 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    float ag[LN_MAXG][4], ab[LN_MAXG][4], g[LN_MAXG][4];
+    float ag[G][4], ab[G][4], g[G][4];
 #pragma unroll
-    for (int i = 0; i < LN_MAXG; ++i)
+    for (int i = 0; i < G; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             ag[i][r] = 0.f;
@@ -204,17 +216,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, 
         const T* xp = reinterpret_cast<const T*>(x.p) + row * x.ld;
         const T* dp = reinterpret_cast<const T*>(dy.p) + t * dy.ld;
         const float mu = mean[t], rs = rstd[t];
-        float xh[LN_MAXG][4], d[LN_MAXG][4];
+        float xh[G][4], d[G][4], prev[G][4];
         float s1 = 0.f, s2 = 0.f;
+        T* op = reinterpret_cast<T*>(const_cast<void*>(dx.p)) + row * dx.ld;
 #pragma unroll
-        for (int i = 0; i < LN_MAXG; ++i) {
+        for (int i = 0; i < G; ++i) {
             const int c = lane * 4 + 256 * i;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { xh[i][r] = 0.f; d[i][r] = 0.f; }
+            for (int r = 0; r < 4; ++r) { xh[i][r] = 0.f; d[i][r] = 0.f; prev[i][r] = 0.f; }
             if (c < C) {
                 float v[4] = {0.f, 0.f, 0.f, 0.f};
                 if (real) Pack<T, 4>::load(xp + c, v);
                 Pack<T, 4>::load(dp + c, d[i]);
+                // the value this pass accumulates onto: fetched WITH the operands, not after the reductions (it was a
+                // second dependent memory round trip per token)
+                if (accumulate && real) Pack<T, 4>::load(op + c, prev[i]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     xh[i][r] = (v[r] - mu) * rs;
@@ -229,27 +245,20 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, 
         s1 = wave_sum(s1) / (float)C;
         s2 = wave_sum(s2) / (float)C;
         if (real) {
-            T* op = reinterpret_cast<T*>(const_cast<void*>(dx.p)) + row * dx.ld;
 #pragma unroll
-            for (int i = 0; i < LN_MAXG; ++i) {
+            for (int i = 0; i < G; ++i) {
                 const int c = lane * 4 + 256 * i;
                 if (c < C) {
                     float o[4];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] * d[i][r] - s1 - xh[i][r] * s2);
-                    if (accumulate) {
-                        float prev[4];
-                        Pack<T, 4>::load(op + c, prev);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] += prev[r];
-                    }
+                    for (int r = 0; r < 4; ++r) o[r] = rs * (g[i][r] * d[i][r] - s1 - xh[i][r] * s2) + prev[i][r];
                     Pack<T, 4>::store(op + c, o);
                 }
             }
         }
     }
 #pragma unroll
-    for (int i = 0; i < LN_MAXG; ++i)
+    for (int i = 0; i < G; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = lane * 4 + 256 * i + r;
@@ -264,6 +273,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, 
         part[((int64_t)blockIdx.x * 2 + 1) * C + c] = red_dyn[1 * Cr + c] + red_dyn[3 * Cr + c] + red_dyn[5 * Cr + c] + red_dyn[7 * Cr + c];
     }
 }
+
+#define YMI_LNB(T, G) hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(blocks), dim3(256), red_bytes, s, xv, dv, ov, T_, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate)
 
 static int ln_bwd_blocks(int64_t T) {
     int64_t b = (T + 31) / 32;  // >= 8 tokens per wave
@@ -281,6 +292,7 @@ extern "C" int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tens
     int64_t Hp = x->h, Wp = x->w;
     if (ws > 0) window_geometry(x, ws, &Hp, &Wp);
     const int64_t T = ws > 0 ? x->n * Hp * Wp : ymi_pixels(x);
+    const int64_t T_ = T;  // (name used by the launch macros)
     YMI_CHECK_ARG(ymi_pixels(dout) == T, "layernorm_bwd: dout must hold %lld tokens", (long long)T);
     const int blocks = ln_bwd_blocks(T);
     const size_t need = (size_t)blocks * 2 * x->c * sizeof(float);
@@ -292,9 +304,9 @@ extern "C" int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tens
     hipStream_t s = (hipStream_t)stream;
     const size_t red_bytes = (size_t)8 * ((x->c + 255) / 256 * 256) * sizeof(float);
     if (x->dtype == YMI_BF16)
-        hipLaunchKernelGGL(layernorm_bwd_kernel<bf16_t>, dim3(blocks), dim3(256), red_bytes, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
+        YMI_LN_G(YMI_LNB, bf16_t);
     else
-        hipLaunchKernelGGL(layernorm_bwd_kernel<float>, dim3(blocks), dim3(256), red_bytes, s, xv, dv, ov, T, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate);
+        YMI_LN_G(YMI_LNB, float);
     YMI_CHECK_LAUNCH("layernorm_bwd");
     return ymi_chan_reduce_final((const float*)workspace, blocks, (int)x->c, dbeta, dgamma, s);
 }
