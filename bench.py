@@ -1,19 +1,25 @@
 """Benchmark of the hot path: images/sec, forward+backward, YOLOv8s-CBAM-Swin, bs=32 per GPU, 640x640.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus N ...            # N > 1 without torchrun's environment: launches itself (see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One step = forward (bf16 autocast) + v8 detection loss + backward (+ RCCL gradient mean over ranks) +
-grad-clip + SGD-nesterov update on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON
-line.  `roofline` is measured live: HIP events on the launch stream around every launch of the MFMA GEMM
-kernels during the timed steps (algorithmic FLOP / elapsed).  `cpu_baseline` times the CPU oracle (a port
-of the reference's PyTorch-CPU path, oracle/) on a bounded sample, rank 0, N=1 only.
+One step = forward (bf16 autocast) + v8 detection loss + backward (+ RCCL gradient mean over ranks) + grad-clip +
+SGD-nesterov update on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
+  roofline      measured live: HIP events on the launch stream around every launch of the MFMA GEMM kernels
+                (algorithmic FLOP / elapsed);
+  forward       north_star's target number: the train-mode forward alone (graph-replayed), ms and MFMA fraction;
+  cpu_baseline  the CPU oracle (a port of the reference's PyTorch-CPU path, oracle/) timed on the host cores on a
+                bounded sample, rank 0, N=1 only (BASELINE.md section 3 protocol).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,62 +33,150 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMG_FWD_BWD = 103.87  # SURVEY.md section 8(d), measured on the reference with FlopCounterMode
+GFLOP_PER_IMG_FWD = 34.68
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
+HOST_SHARE = 16  # host cores that belong to one GPU of the box (the pool's rule for worker sizing)
 
 
-def cpu_baseline(batch=4, iters=8):
-    """reference's CPU path as restated by the oracle: fwd + v8 loss + bwd, fp32, all host cores."""
+def self_launch(args):
+    """`bench.py --gpus N` started by hand (no torchrun environment): start N ranks as CHILD processes through
+    torch.distributed.run - before this process has made any GPU call, never by re-executing it - relay their output
+    (rank 0 prints the JSON line) and return their exit code.  Reference launcher: ultralytics/utils/dist.py:78-98."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS=os.environ.get("OMP_NUM_THREADS", "4"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def host_info():
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    return model, avail
+
+
+def cpu_baseline():
+    """reference's CPU path as restated by the oracle, BASELINE.md section 3 protocol: forward-only (train-mode BN,
+    no_grad) at bs=32 and forward + v8 loss + backward at bs=8, fp32 NCHW, 1 warm-up + up to 3 timed iterations each
+    (each leg stops early after 20 s of timed work), same synthetic batch recipe as the GPU run."""
+    from improving_yolov8_cbam_swinblock_amd.engine.trainer import synthetic_batch
     from oracle.loss import v8DetectionLoss
     from oracle.tasks import DetectionModel
 
-    # the GPU box gives one GPU's share of the host (16 cores); os.cpu_count() reports the whole machine
-    threads = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    cpu_model, avail = host_info()
+    threads = min(HOST_SHARE, avail)  # one GPU's share of the host; the machine's other cores belong to other boxes
     torch.set_num_threads(threads)
     torch.manual_seed(0)
     model = DetectionModel("yolov8s.yaml", ch=3, nc=1)
     model.train()
     crit = v8DetectionLoss(model)
-    g = torch.Generator().manual_seed(1)
-    img = torch.rand(batch, 3, 640, 640, generator=g)
-    n = batch * 4
-    tb = {
-        "batch_idx": torch.arange(batch).repeat_interleave(4).float(),
-        "cls": torch.zeros(n, 1),
-        "bboxes": torch.cat((torch.rand(n, 2, generator=g) * 0.6 + 0.2, torch.rand(n, 2, generator=g) * 0.3 + 0.05), 1),
-    }
 
-    def step():
-        loss, _ = crit(model(img), tb)
+    def timed(fn, iters=3, budget=20.0):
+        fn()  # warm-up
+        t0 = time.perf_counter()
+        done = 0
+        for _ in range(iters):
+            fn()
+            done += 1
+            if time.perf_counter() - t0 > budget:
+                break
+        return done, time.perf_counter() - t0
+
+    b32 = synthetic_batch(32, 640, torch.device("cpu"), 1)
+    b8 = synthetic_batch(8, 640, torch.device("cpu"), 1)
+
+    def fwd():
+        with torch.no_grad():
+            model(b32["img"])
+
+    def fwd_bwd():
+        loss, _ = crit(model(b8["img"]), b8)
         loss.sum().backward()
         model.zero_grad(set_to_none=True)
 
-    step()  # warm-up
-    t0 = time.perf_counter()
-    done = 0
-    for _ in range(iters):
-        step()
-        done += 1
-        if time.perf_counter() - t0 > 30.0:  # bounded sample
-            break
-    dt = time.perf_counter() - t0
-    iters = done
+    nf, tf = timed(fwd)
+    nb, tb = timed(fwd_bwd)
     return {
-        "value": round(batch * iters / dt, 3),
+        "value": round(8 * nb / tb, 3),
         "unit": "images/sec",
         "cores": threads,
         "kind": "port",
-        "sample": f"oracle (CPU restatement of the reference path) fwd+loss+bwd fp32, bs={batch} 640x640, 1 warm-up + {iters} timed iterations",
+        "cpu_model": cpu_model,
+        "logical_cpus_visible": avail,
+        "forward_only": {"value": round(32 * nf / tf, 3), "unit": "images/sec", "batch": 32, "iterations": nf},
+        "sample": (f"oracle (CPU restatement of the reference path, fp32 NCHW) on {threads} threads of '{cpu_model}': value = forward + v8 loss + "
+                   f"backward at bs=8 640x640 (1 warm-up + {nb} timed); forward_only = train-mode forward, no_grad, bs=32 (1 warm-up + {nf} timed)"),
     }
 
 
-def traffic_bytes(family):
-    """HBM bytes per launch of the kernel family from the committed PMC passes (tools/pmc_traffic.py); None if absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    try:
-        with open(path) as fh:
-            return json.load(fh)["families"][family]["hbm_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        return None
+def kernel_rev():
+    """hash of the kernel sources: PMC traffic measured on other kernels is not reported for these."""
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "improving_yolov8_cbam_swinblock_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
+def traffic_record(family):
+    """HBM bytes per launch from the latest committed PMC passes (tools/pmc_traffic.py) IF they were taken on the
+    kernels this run executes (same source hash); otherwise None: hardware counters cannot be read from inside the run."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("pmc_traffic.json"):
+            try:
+                with open(os.path.join(pdir, name)) as fh:
+                    d = json.load(fh)
+                if d.get("kernel_rev") == kernel_rev():
+                    best = (d["families"][family]["hbm_bytes_per_launch"], name)
+            except (OSError, KeyError, ValueError):
+                continue
+    return best
+
+
+def forward_record(model, batch, steps):
+    """north_star's target metric: the train-mode forward of the step alone (bf16 autocast, batch statistics, tensors
+    saved for backward, weight pack included), replayed as a HIP graph; 1.110 TFLOP per batch of 32."""
+    model.train()
+
+    def fwd():
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            return model(batch["img"])
+
+    for _ in range(2):
+        fwd()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd()
+    del out
+    for _ in range(3):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    del g
+    n = batch["img"].shape[0]
+    tf = n * GFLOP_PER_IMG_FWD / 1e3 / (ms * 1e-3)
+    return {"ms": round(ms, 3), "images_per_sec": round(n / (ms * 1e-3), 1), "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4),
+            "target_mfma_frac": 0.40, "what": f"train-mode forward (Detect maps), bs={n}, bf16, HIP-graph replay, {steps} timed replays"}
 
 
 def main():
@@ -95,8 +189,12 @@ def main():
     ap.add_argument("--model", default="yolov8s.yaml")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-forward", action="store_true", help="skip the forward-only sub-record")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a HIP graph (several ranks: forward+backward graph, RCCL mean + update eager), 0: eager")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))  # no GPU call has happened in this process
 
     from improving_yolov8_cbam_swinblock_amd import _lib
     from improving_yolov8_cbam_swinblock_amd.engine import ddp
@@ -154,6 +252,7 @@ def main():
         fam = 0 if ms[0] >= ms[1] else 1
         names = ["igemm_kernel (implicit-GEMM conv fwd / dgrad / token GEMM)", "wgrad_kernel (weight-gradient split-K GEMM)"]
         ach = fl[fam] / (ms[fam] * 1e-3) / 1e12 if ms[fam] > 0 else 0.0
+        tr = traffic_record(["igemm", "wgrad"][fam])
         roof = {
             "bound": "mfma",
             "kernel": names[fam],
@@ -161,8 +260,12 @@ def main():
             "peak": PEAK_BF16_TFLOPS,
             "unit": "TFLOP/s",
             "frac": round(ach / PEAK_BF16_TFLOPS, 4),
-            "traffic": traffic_bytes(["igemm", "wgrad"][fam]),
-            "traffic_unit": "HBM bytes per launch (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/r01_pmc_traffic.json)",
+            # hardware counters cannot be sampled from inside this process: the figure comes from separate rocprofv3 --pmc
+            # passes of this same command (tools/pmc_traffic.py) and is reported only when those passes ran the kernels of
+            # this source revision
+            "traffic": tr[0] if tr else None,
+            "traffic_source": (f"profiles/{tr[1]} (HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE KiB, kernel_rev {kernel_rev()})" if tr
+                               else f"no PMC pass committed for kernel_rev {kernel_rev()}"),
             "algorithmic_bytes_per_launch": round(byt[fam] / max(cnt[fam], 1)),
             # every launch against ITS OWN roofline, max(flop / 2.5 PF, algorithmic bytes / 8 TB/s): the 1x1 and
             # narrow convs of this model are HBM-bound, so the family's MFMA fraction alone understates them
@@ -182,6 +285,9 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     value = args.gpus * args.batch * args.steps / dt
+    fwd = None
+    if rank == 0 and not args.no_forward and args.model == "yolov8s.yaml":
+        fwd = forward_record(model, batch, max(args.steps, 10))
     if rank == 0:
         out = {
             # BASELINE.json's metric on its configuration; other --model / --batch / --imgsz values are named as they are
@@ -199,7 +305,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.model} (CBAM + 2x SwinBlock + SPPF5 + SPPF7, nc=1) forward + v8 loss + backward + SGD step, bs={args.batch}/GPU {args.imgsz}x{args.imgsz}",
+                "workload": f"{args.model} (CBAM + 2x SwinBlock + SPPF5 + SPPF7, nc=1) forward + v8 loss + backward + clip + SGD-nesterov step, bs={args.batch}/GPU {args.imgsz}x{args.imgsz}",
                 "global_batch": args.batch * args.gpus,
                 "imgsz": args.imgsz,
                 "parallelism": f"dp{args.gpus}",
@@ -211,6 +317,8 @@ def main():
         }
         if roof:
             out["roofline"] = roof
+        if fwd:
+            out["forward"] = fwd
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -214,6 +214,8 @@ _workspaces = {}
 
 def workspace(nbytes, device, tag="default"):
     """grow-only scratch buffer per (device, stream, tag); contents are undefined between calls."""
+    if os.environ.get("YMI_WS_NOCACHE") == "1":
+        return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
     key = (device.index, torch.cuda.current_stream().cuda_stream, tag)
     buf = _workspaces.get(key)
     if buf is None or buf.numel() < nbytes:

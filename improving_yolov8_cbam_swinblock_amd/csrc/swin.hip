@@ -800,13 +800,322 @@ __global__ __launch_bounds__(256) void window_attn_bwd_tr_kernel(AttnArgs a) {
         }
 }
 
+// ---- windows of more than 64 tokens (any window_size: swin_block.py:24) and head dims the one-tile kernels cannot hold ----
+// Flash-style tiling: 64-query x 64-key tiles, online softmax in the forward, P recomputed from the saved log-sum-exp in the
+// backward (one kernel accumulates dQ over key tiles, one accumulates dK / dV over query tiles: no atomics, deterministic).
+// The head dimension is walked in chunks of ATT_HC columns through two LDS staging buffers, so float32 at head_dim 192
+// fits the 160 KiB of a CU.  This path serves config 5's optional ws = 14 row (196 tokens); the 49-token windows of the
+// benchmark stay on the one-tile kernels above.
+constexpr int ATT_HC = 96;
+
+template <typename T> struct TiledLds {
+    static constexpr int ES = (int)sizeof(T);
+    static constexpr int PAD = AT<T>::PAD;
+    static constexpr int RS = (ATT_HC + PAD) * ES;  // row stride of a [64][chunk] image
+    static constexpr int TS = (64 + PAD) * ES;      // row stride of a [chunk][64] / [64][64] image
+    static constexpr size_t STAGE = (size_t)(64 * RS > ATT_HC * TS ? 64 * RS : ATT_HC * TS);
+};
+
+// delta[m] = sum_d dO[m][d] * O[m][d] for the 64 rows starting at row r0 of the window (zero beyond the window)
+template <typename T>
+__device__ __forceinline__ void attn_delta_rows(float* delta, const T* dO, int64_t ldd, const T* o, int64_t ldo, int rows, int hd) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int m = wv; m < 64; m += 4) {
+        float acc = 0.f;
+        if (m < rows)
+            for (int d = lane; d < hd; d += 64) acc += to_f32(dO[(int64_t)m * ldd + d]) * to_f32(o[(int64_t)m * ldo + d]);
+        acc = wave_sum(acc);
+        if (lane == 0) delta[m] = acc;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_attn_tiled_fwd_kernel(AttnArgs a) {
+    typedef TiledLds<T> LD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* GA = smem;
+    char* GB = GA + LD::STAGE;
+    char* P = GB + LD::STAGE;                                          // [64 queries][64 keys]
+    float* al = reinterpret_cast<float*>(P + (size_t)64 * LD::TS);     // [64] rescale factor of this key tile / final 1/l
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int L = a.L, hd = a.hd;
+    const int head = blockIdx.y, co = head * hd;
+    const int q0 = blockIdx.z * 64, qrows = (L - q0 < 64) ? L - q0 : 64;
+    const int64_t t0 = (int64_t)blockIdx.x * L;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
+    T* out = reinterpret_cast<T*>(const_cast<void*>(a.out.p)) + t0 * a.out.ld;
+    const int ndt = (hd + 15) / 16;
+    f32x4 o[ATT_MAXDT];
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run = -__builtin_inff(), l_run = 0.f;  // of query q0 + 16*wv + l15 (replicated in the 4 lanes that share it)
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        const int krows = (L - k0 < 64) ? L - k0 : 64;
+        // S^T tile: A = K rows (i = key), B = Q rows (j = query)
+        f32x4 s[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int d0 = 0; d0 < hd; d0 += ATT_HC) {
+            const int hc = (hd - d0 < ATT_HC) ? hd - d0 : ATT_HC, hcp = (hc + 31) / 32 * 32;
+            __syncthreads();
+            lds_load_rows<T>(GA, qkv + (int64_t)q0 * a.qkv.ld + co + d0, a.qkv.ld, qrows, hc, hcp);
+            lds_load_rows<T>(GB, qkv + (int64_t)k0 * a.qkv.ld + a.C + co + d0, a.qkv.ld, krows, hc, hcp);
+            __syncthreads();
+            const int rs = (hcp + AT<T>::PAD) * LD::ES;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) AT<T>::mma(GB, rs, t * 16, GA, rs, wv * 16, hcp, lane, s[t]);
+        }
+        float mx = -__builtin_inff();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * t + 4 * l4 + r;
+                s[t][r] = j < krows ? s[t][r] * a.scale : -__builtin_inff();
+                mx = fmaxf(mx, s[t][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);  // first tile: exp(-inf) = 0
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                s[t][r] = __expf(s[t][r] - m_new);
+                sum += s[t][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        l_run = l_run * alpha + sum;
+        m_run = m_new;
+        const int m = 16 * wv + l15;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float p[4] = {s[t][0], s[t][1], s[t][2], s[t][3]};
+            Pack<T, 4>::store(reinterpret_cast<T*>(P + (size_t)m * LD::TS) + 16 * t + 4 * l4, p);
+        }
+        if (l4 == 0) al[m] = alpha;
+        __syncthreads();
+        float ar[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ar[r] = al[16 * wv + 4 * l4 + r];
+#pragma unroll
+        for (int dt = 0; dt < ATT_MAXDT; ++dt)
+            if (dt < ndt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[dt][r] *= ar[r];
+        // O += P V: A = P rows (i = query), B = V^T rows (j = d)
+        for (int d0 = 0; d0 < hd; d0 += ATT_HC) {
+            const int hc = (hd - d0 < ATT_HC) ? hd - d0 : ATT_HC, hcp = (hc + 31) / 32 * 32;
+            __syncthreads();
+            lds_load_transposed<T>(GA, qkv + (int64_t)k0 * a.qkv.ld + 2 * a.C + co + d0, a.qkv.ld, krows, hc, hcp);
+            __syncthreads();
+#pragma unroll
+            for (int dt = 0; dt < ATT_MAXDT; ++dt)
+                if (dt < ndt && dt * 16 >= d0 && dt * 16 < d0 + ATT_HC) AT<T>::mma(P, LD::TS, wv * 16, GA, LD::TS, dt * 16 - d0, 64, lane, o[dt]);
+        }
+        __syncthreads();  // P / al are rewritten by the next key tile
+    }
+    const int m = 16 * wv + l15;
+    if (l4 == 0) {
+        al[m] = 1.f / l_run;
+        if (m < qrows && a.lse) a.lse[(t0 + q0 + m) * a.heads + head] = m_run + __logf(l_run);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt)
+        if (dt < ndt) {
+            const int d = dt * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mq = 16 * wv + 4 * l4 + r;
+                if (mq < qrows && d < hd) out[(int64_t)(q0 + mq) * a.out.ld + co + d] = from_f32<T>(o[dt][r] * al[mq]);
+            }
+        }
+}
+
+// S and dP of one (query tile, key tile) pair, then P = exp(S*scale - lse), dS = P (dP - delta) scale.
+// Lane layout of the results: queries m = 16*wv + 4*l4 + r, key j = 16*t + l15.
+template <typename T>
+__device__ __forceinline__ void attn_tile_p_ds(const AttnArgs& a, char* GA, char* GB, const T* qkv, const T* dO, int q0, int qrows, int k0, int krows, int co,
+                                               int64_t trow0, int head, const float* delta, float (&p)[4][4], float (&ds)[4][4]) {
+    typedef TiledLds<T> LD;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int hd = a.hd;
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int d0 = 0; d0 < hd; d0 += ATT_HC) {
+        const int hc = (hd - d0 < ATT_HC) ? hd - d0 : ATT_HC, hcp = (hc + 31) / 32 * 32;
+        const int rs = (hcp + AT<T>::PAD) * LD::ES;
+        __syncthreads();
+        lds_load_rows<T>(GA, qkv + (int64_t)q0 * a.qkv.ld + co + d0, a.qkv.ld, qrows, hc, hcp);          // Q
+        lds_load_rows<T>(GB, qkv + (int64_t)k0 * a.qkv.ld + a.C + co + d0, a.qkv.ld, krows, hc, hcp);  // K
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) AT<T>::mma(GA, rs, wv * 16, GB, rs, t * 16, hcp, lane, s[t]);
+        __syncthreads();
+        lds_load_rows<T>(GA, dO + (int64_t)q0 * a.dout.ld + co + d0, a.dout.ld, qrows, hc, hcp);           // dO
+        lds_load_rows<T>(GB, qkv + (int64_t)k0 * a.qkv.ld + 2 * a.C + co + d0, a.qkv.ld, krows, hc, hcp);  // V
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t) AT<T>::mma(GA, rs, wv * 16, GB, rs, t * 16, hcp, lane, dp[t]);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 16 * wv + 4 * l4 + r;
+        const float lse = m < qrows ? a.lse[(trow0 + q0 + m) * a.heads + head] : 0.f;
+        const float dl = delta[m];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const bool ok = (16 * t + l15 < krows) && (m < qrows);
+            p[t][r] = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
+            ds[t][r] = ok ? p[t][r] * (dp[t][r] - dl) * a.scale : 0.f;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_attn_tiled_dq_kernel(AttnArgs a) {
+    typedef TiledLds<T> LD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* GA = smem;
+    char* GB = GA + LD::STAGE;
+    char* DS = GB + LD::STAGE;                                          // [64 queries][64 keys]
+    float* delta = reinterpret_cast<float*>(DS + (size_t)64 * LD::TS);  // [64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int L = a.L, hd = a.hd;
+    const int head = blockIdx.y, co = head * hd;
+    const int q0 = blockIdx.z * 64, qrows = (L - q0 < 64) ? L - q0 : 64;
+    const int64_t t0 = (int64_t)blockIdx.x * L;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
+    const T* ov = reinterpret_cast<const T*>(a.out.p) + t0 * a.out.ld;
+    const T* dO = reinterpret_cast<const T*>(a.dout.p) + t0 * a.dout.ld;
+    T* dqkv = reinterpret_cast<T*>(const_cast<void*>(a.dqkv.p)) + t0 * a.dqkv.ld;
+    const int ndt = (hd + 15) / 16;
+    attn_delta_rows<T>(delta, dO + (int64_t)q0 * a.dout.ld + co, a.dout.ld, ov + (int64_t)q0 * a.out.ld + co, a.out.ld, qrows, hd);
+    f32x4 dq[ATT_MAXDT];
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k0 = 0; k0 < L; k0 += 64) {
+        const int krows = (L - k0 < 64) ? L - k0 : 64;
+        float p[4][4], ds[4][4];
+        attn_tile_p_ds<T>(a, GA, GB, qkv, dO, q0, qrows, k0, krows, co, t0, head, delta, p, ds);
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) reinterpret_cast<T*>(DS + (size_t)(16 * wv + 4 * l4 + r) * LD::TS)[16 * t + l15] = from_f32<T>(ds[t][r]);
+        // dQ[m][d] += sum_j dS[m][j] K^T[d][j]
+        for (int d0 = 0; d0 < hd; d0 += ATT_HC) {
+            const int hc = (hd - d0 < ATT_HC) ? hd - d0 : ATT_HC, hcp = (hc + 31) / 32 * 32;
+            __syncthreads();
+            lds_load_transposed<T>(GA, qkv + (int64_t)k0 * a.qkv.ld + a.C + co + d0, a.qkv.ld, krows, hc, hcp);
+            __syncthreads();
+#pragma unroll
+            for (int dt = 0; dt < ATT_MAXDT; ++dt)
+                if (dt < ndt && dt * 16 >= d0 && dt * 16 < d0 + ATT_HC) AT<T>::mma(DS, LD::TS, wv * 16, GA, LD::TS, dt * 16 - d0, 64, lane, dq[dt]);
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt)
+        if (dt < ndt) {
+            const int d = dt * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * wv + 4 * l4 + r;
+                if (m < qrows && d < hd) dqkv[(int64_t)(q0 + m) * a.dqkv.ld + co + d] = from_f32<T>(dq[dt][r]);
+            }
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void window_attn_tiled_dkv_kernel(AttnArgs a) {
+    typedef TiledLds<T> LD;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* GA = smem;
+    char* GB = GA + LD::STAGE;
+    char* PT = GB + LD::STAGE;                                           // P^T  [64 keys][64 queries]
+    char* DST = PT + (size_t)64 * LD::TS;                                // dS^T [64 keys][64 queries]
+    float* delta = reinterpret_cast<float*>(DST + (size_t)64 * LD::TS);  // [64]
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    const int L = a.L, hd = a.hd;
+    const int head = blockIdx.y, co = head * hd;
+    const int k0 = blockIdx.z * 64, krows = (L - k0 < 64) ? L - k0 : 64;
+    const int64_t t0 = (int64_t)blockIdx.x * L;
+    const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
+    const T* ov = reinterpret_cast<const T*>(a.out.p) + t0 * a.out.ld;
+    const T* dO = reinterpret_cast<const T*>(a.dout.p) + t0 * a.dout.ld;
+    T* dqkv = reinterpret_cast<T*>(const_cast<void*>(a.dqkv.p)) + t0 * a.dqkv.ld;
+    const int ndt = (hd + 15) / 16;
+    f32x4 dk[ATT_MAXDT], dv[ATT_MAXDT];
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt) {
+        dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int q0 = 0; q0 < L; q0 += 64) {
+        const int qrows = (L - q0 < 64) ? L - q0 : 64;
+        __syncthreads();  // delta / PT / DST of the previous query tile are no longer read
+        attn_delta_rows<T>(delta, dO + (int64_t)q0 * a.dout.ld + co, a.dout.ld, ov + (int64_t)q0 * a.out.ld + co, a.out.ld, qrows, hd);
+        float p[4][4], ds[4][4];
+        attn_tile_p_ds<T>(a, GA, GB, qkv, dO, q0, qrows, k0, krows, co, t0, head, delta, p, ds);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int j = 16 * t + l15;
+            float pv[4] = {p[t][0], p[t][1], p[t][2], p[t][3]}, dv4[4] = {ds[t][0], ds[t][1], ds[t][2], ds[t][3]};
+            Pack<T, 4>::store(reinterpret_cast<T*>(PT + (size_t)j * LD::TS) + 16 * wv + 4 * l4, pv);
+            Pack<T, 4>::store(reinterpret_cast<T*>(DST + (size_t)j * LD::TS) + 16 * wv + 4 * l4, dv4);
+        }
+        for (int d0 = 0; d0 < hd; d0 += ATT_HC) {
+            const int hc = (hd - d0 < ATT_HC) ? hd - d0 : ATT_HC, hcp = (hc + 31) / 32 * 32;
+            __syncthreads();
+            lds_load_transposed<T>(GA, dO + (int64_t)q0 * a.dout.ld + co + d0, a.dout.ld, qrows, hc, hcp);  // dO^T [d][m]
+            lds_load_transposed<T>(GB, qkv + (int64_t)q0 * a.qkv.ld + co + d0, a.qkv.ld, qrows, hc, hcp);   // Q^T  [d][m]
+            __syncthreads();
+#pragma unroll
+            for (int dt = 0; dt < ATT_MAXDT; ++dt)
+                if (dt < ndt && dt * 16 >= d0 && dt * 16 < d0 + ATT_HC) {
+                    AT<T>::mma(PT, LD::TS, wv * 16, GA, LD::TS, dt * 16 - d0, 64, lane, dv[dt]);   // dV[j][d] += sum_m P^T[j][m] dO^T[d][m]
+                    AT<T>::mma(DST, LD::TS, wv * 16, GB, LD::TS, dt * 16 - d0, 64, lane, dk[dt]);  // dK[j][d] += sum_m dS^T[j][m] Q^T[d][m]
+                }
+        }
+    }
+#pragma unroll
+    for (int dt = 0; dt < ATT_MAXDT; ++dt)
+        if (dt < ndt) {
+            const int d = dt * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = 16 * wv + 4 * l4 + r;
+                if (j < krows && d < hd) {
+                    T* dst = dqkv + (int64_t)(k0 + j) * a.dqkv.ld + co + d;
+                    dst[a.C] = from_f32<T>(dk[dt][r]);
+                    dst[2 * a.C] = from_f32<T>(dv[dt][r]);
+                }
+            }
+        }
+}
+
+template <typename T> static size_t tiled_lds(bool bwd_kv) {
+    return 2 * TiledLds<T>::STAGE + (size_t)(bwd_kv ? 2 : 1) * 64 * TiledLds<T>::TS + 64 * sizeof(float);
+}
+
 static int attn_common(const ymi_tensor* qkv, int64_t wlen, int64_t heads, AttnArgs* a, size_t* lds, bool bwd, const char* what) {
     YMI_CHECK_ARG(ymi_tensor_ok(qkv) && wlen > 0 && heads > 0, "%s: args", what);
     YMI_CHECK_ARG(qkv->c % 3 == 0, "%s: qkv must have 3C channels", what);
     const int64_t C = qkv->c / 3;
     YMI_CHECK_ARG(C % heads == 0, "%s: C %% heads", what);
     const int64_t hd = C / heads;
-    YMI_CHECK_ARG(wlen <= 64, "%s: window of %lld tokens exceeds the 64-token tile of this kernel", what, (long long)wlen);
     YMI_CHECK_ARG(hd % 4 == 0 && hd <= 16 * ATT_MAXDT && qkv->ld % 4 == 0, "%s: head_dim must be a multiple of 4 and <= %d", what, 16 * ATT_MAXDT);
     YMI_CHECK_ARG(ymi_pixels(qkv) % wlen == 0, "%s: token count not a multiple of the window length", what);
     a->L = (int)wlen; a->heads = (int)heads; a->C = (int)C; a->hd = (int)hd; a->hdp = (int)((hd + 31) / 32 * 32);
@@ -814,11 +1123,7 @@ static int attn_common(const ymi_tensor* qkv, int64_t wlen, int64_t heads, AttnA
     const int es = (int)ymi_esize(qkv->dtype), pad = qkv->dtype == YMI_BF16 ? 8 : 4;
     const size_t rs = (size_t)(a->hdp + pad) * es, ts = (size_t)(64 + pad) * es;
     const size_t gsz = 64 * rs > a->hdp * ts ? 64 * rs : a->hdp * ts;
-    *lds = 2 * gsz + (bwd ? 3 : 1) * 64 * ts + (bwd ? 64 * sizeof(float) : 0);
-    if (*lds > 160 * 1024) {
-        ymi_set_error("%s: head_dim %lld needs %zu B of LDS (> 160 KiB) in this dtype", what, (long long)hd, *lds);
-        return YMI_EINVAL;
-    }
+    *lds = 2 * gsz + (bwd ? 3 : 1) * 64 * ts + (bwd ? 64 * sizeof(float) : 0);  // one-tile kernels; > 160 KiB or wlen > 64: tiled kernels
     return YMI_OK;
 }
 
@@ -831,8 +1136,18 @@ extern "C" int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.lse = lse;
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
     static const int attn_tr = getenv("YMI_ATTN_TR") ? atoi(getenv("YMI_ATTN_TR")) : 1;  // 0: the generic (f32-style) kernel for bf16 too
+    static const int attn_tiled = getenv("YMI_ATTN_TILED") ? atoi(getenv("YMI_ATTN_TILED")) : 0;  // 1: tiled kernels for every window size (tests)
     const size_t lds_tr = (size_t)3 * 64 * (a.hdp + 8) * 2 + (size_t)64 * (64 + 8) * 2;
-    if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
+    if (wlen > 64 || lds > 160 * 1024 || attn_tiled) {
+        dim3 tg(grid.x, grid.y, (unsigned)((wlen + 63) / 64));
+        if (qkv->dtype == YMI_BF16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_tiled_fwd_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(window_attn_tiled_fwd_kernel<bf16_t>, tg, dim3(256), tiled_lds<bf16_t>(false), (hipStream_t)stream, a);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_tiled_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            hipLaunchKernelGGL(window_attn_tiled_fwd_kernel<float>, tg, dim3(256), tiled_lds<float>(false), (hipStream_t)stream, a);
+        }
+    } else if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_fwd_tr_kernel, grid, dim3(256), lds_tr, (hipStream_t)stream, a);
     } else if (qkv->dtype == YMI_BF16) {
@@ -860,8 +1175,21 @@ extern "C" int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor*
     a.lse = const_cast<float*>(lse);
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
     static const int attn_tr = getenv("YMI_ATTN_TR") ? atoi(getenv("YMI_ATTN_TR")) : 1;  // 0: the generic (f32-style) kernel for bf16 too
+    static const int attn_tiled = getenv("YMI_ATTN_TILED") ? atoi(getenv("YMI_ATTN_TILED")) : 0;
     const size_t lds_tr = (size_t)4 * 64 * (a.hdp + 8) * 2 + (size_t)2 * 64 * (64 + 8) * 2;
-    if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
+    if (wlen > 64 || lds > 160 * 1024 || attn_tiled) {
+        dim3 tg(grid.x, grid.y, (unsigned)((wlen + 63) / 64));
+#define YMI_TILED_BWD(T)                                                                                                                          \
+    do {                                                                                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_tiled_dq_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_tiled_dkv_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL(window_attn_tiled_dq_kernel<T>, tg, dim3(256), tiled_lds<T>(false), (hipStream_t)stream, a);                             \
+        hipLaunchKernelGGL(window_attn_tiled_dkv_kernel<T>, tg, dim3(256), tiled_lds<T>(true), (hipStream_t)stream, a);                             \
+    } while (0)
+        if (qkv->dtype == YMI_BF16) YMI_TILED_BWD(bf16_t);
+        else YMI_TILED_BWD(float);
+#undef YMI_TILED_BWD
+    } else if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_bwd_tr_kernel, grid, dim3(256), lds_tr, (hipStream_t)stream, a);
     } else if (qkv->dtype == YMI_BF16) {

@@ -107,7 +107,11 @@ class TrainStep:
         else:
             for k, v in batch.items():
                 if torch.is_tensor(v) and v is not self._static[k]:
+                    if v.shape != self._static[k].shape:  # copy_ would broadcast silently (e.g. a shorter label tensor)
+                        raise ValueError(f"graph=True replays static shapes: batch['{k}'] is {tuple(v.shape)}, captured {tuple(self._static[k].shape)}")
                     self._static[k].copy_(v)
+                elif not torch.is_tensor(v) and v != self._static[k]:
+                    raise ValueError(f"graph=True: batch['{k}'] = {v!r} differs from the captured value {self._static[k]!r}")
         self._graph.replay()
         if not self.full_graph:
             self._reduce_and_update(self._graph_grads)

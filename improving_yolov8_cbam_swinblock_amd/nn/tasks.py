@@ -156,6 +156,8 @@ class BaseModel(nn.Module):
         arena = getattr(self, "_arena", None)
         if arena is None or (arena.dtype is not None and arena.dtype != dt):
             arena = self._arena = ops.WeightArena()
+        elif arena.built and arena.stale():  # parameter storage moved (model.to(), .float(), ...): start over
+            arena = self._arena = ops.WeightArena()
         elif not arena.built and arena.specs:
             arena.build()
         ops.set_weight_arena(arena)
@@ -170,6 +172,7 @@ class BaseModel(nn.Module):
                     m.conv = fuse_conv_and_bn(m.conv, m.bn)
                     delattr(m, "bn")
                     m.forward = m.forward_fuse
+            self._arena = None
         return self
 
     def is_fused(self, thresh=10):
@@ -179,6 +182,7 @@ class BaseModel(nn.Module):
     def _apply(self, fn):
         """keep Detect's stride / anchors on the model's device (reference tasks.py:264-282)."""
         self = super()._apply(fn)
+        self._arena = None  # packed operands and their descriptor table refer to the old parameter storage
         m = self.model[-1]
         if isinstance(m, Detect):
             m.stride = fn(m.stride)

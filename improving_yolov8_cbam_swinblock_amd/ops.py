@@ -166,18 +166,37 @@ class WeightArena:
         self.starts = torch.tensor(starts, dtype=torch.int32).to(dev)
         self.count, self.blocks = len(plan), starts[-1]
         self.params = [sp["weight"] for _, sp, *_ in plan]
+        self.ptrs = [w.data_ptr() for w in self.params]  # the descriptor table holds these raw addresses
         self.built = True
+
+    def stale(self):
+        """a parameter's storage moved since build() (model.to() / .float() / any re-allocating Module._apply swaps
+        param.data under the same Parameter object): the descriptor table then points at freed memory."""
+        return any(w.data_ptr() != p or w.device != self.arena.device for w, p in zip(self.params, self.ptrs))
 
     def pack(self):
         check(L().ymi_pack_conv_weights_batch(ptr(self.descs), ptr(self.starts), self.count, self.blocks, ymi_dtype(self.dtype), stream_ptr()), "pack_conv_weights_batch")
+        # an operand is valid for exactly the weight VALUES it was packed from: Tensor._version counts in-place
+        # updates (optimizer steps, load_state_dict), so a module called on its own after an update never sees the
+        # operands of the previous step
+        self.versions = {id(w): w._version for w in self.params}
         self.fresh = True
 
+    def _view(self, weight, dtype):
+        if not (self.built and self.fresh and dtype == self.dtype):
+            return None
+        key = id(weight)
+        v = self.views.get(key)
+        if v is None or self.versions.get(key) != weight._version:
+            return None
+        return v
+
     def lookup_fwd(self, weight, ipad, dtype):
-        v = self.views.get(id(weight)) if (self.built and self.fresh and dtype == self.dtype) else None
+        v = self._view(weight, dtype)
         return v[0] if v is not None and v[0] is not None and v[2] == ipad else None
 
     def lookup_dgrad(self, weight, opad, stride, dtype):
-        v = self.views.get(id(weight)) if (self.built and self.fresh and dtype == self.dtype) else None
+        v = self._view(weight, dtype)
         return v[1] if v is not None and v[1] is not None and v[3] == opad and v[4] == stride else None
 
 
@@ -195,6 +214,7 @@ def pack_conv_fwd(weight, cin_pad, dtype):
         if hit is not None:
             return hit
         _arena.note(weight, dtype, ipad=cin_pad)
+    weight = _as4d(weight)
     o, i, kh, kw = weight.shape
     buf = torch.empty(o * kh * kw * cin_pad, dtype=dtype, device=weight.device)
     check(L().ymi_pack_conv_weight_fwd(ptr(weight.detach()), o, i, kh, kw, cin_pad, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_fwd")
@@ -207,6 +227,7 @@ def pack_conv_dgrad(weight, cout_pad, stride, dtype):
         if hit is not None:
             return hit
         _arena.note(weight, dtype, opad=cout_pad, stride=stride)
+    weight = _as4d(weight)
     o, i, kh, kw = weight.shape
     buf = torch.empty(cout_pad * i * kh * kw, dtype=dtype, device=weight.device)
     check(L().ymi_pack_conv_weight_dgrad_ex(ptr(weight.detach()), o, cout_pad, i, kh, kw, stride, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_dgrad")
@@ -423,7 +444,7 @@ class _ConvAffineAct(torch.autograd.Function):
         w4 = _as4d(weight)
         o, i, k, _ = w4.shape
         dev = x.device
-        wp = pack_conv_fwd(w4, x.shape[1], dtype)
+        wp = pack_conv_fwd(weight, x.shape[1], dtype)
         if x.dim() == 4:
             n, cp, h, w = x.shape
             ho, wo = _conv_out_hw(h, w, k, stride)
@@ -465,7 +486,7 @@ class _ConvAffineAct(torch.autograd.Function):
                 dx = _dgrad(dy, w4, k, stride, x.shape, dtype)
             else:
                 ty = as_ymi(dy)
-                wd = pack_conv_dgrad(w4, ty.c, 1, dtype)
+                wd = pack_conv_dgrad(weight, ty.c, 1, dtype)
                 dx = torch.empty((x.shape[0], x.shape[1]), dtype=dtype, device=x.device)
                 check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), x.shape[1], 1, 1, 1, _byref(as_ymi(dx)), stream_ptr()), "conv2d_bwd_data")
         dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias)

@@ -41,3 +41,45 @@ def _seed():
     torch.manual_seed(0)
     np.random.seed(0)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
+
+
+LARGE_SWIN = ["swin_d384_14x14", "swin_d384_20x20", "swin_d64_ws14_20x20", "swin_d64_ws14_28x14", "swin_d384_ws14_28x28"]
+
+
+def load_large_swin(name, ctor):
+    """a LARGE_SWIN fixture (tests/golden/make_golden.py::swin_large_fixtures) -> (module with the fixture's weights,
+    x, gy, expected).  ctor(dim, heads, ws) builds the SwinBlock under test.  Seeded cases rebuild weights and inputs
+    from the seed (tests/golden_weights.py); their parameter gradients are strided samples + norms."""
+    from golden_weights import seeded_inputs, seeded_state
+
+    d = load_golden(name)
+    dim, heads, ws, B, H, W, seed, seeded = (int(v) for v in d["meta"])
+    m = ctor(dim, heads, ws)
+    if seeded:
+        m.load_state_dict(seeded_state({k: tuple(v.shape) for k, v in m.state_dict().items()}, seed), strict=True)
+        x, gy = seeded_inputs(seed, (B, dim, H, W), (B, dim, H, W))
+    else:
+        m.load_state_dict(golden_state(d), strict=True)
+        x, gy = torch.from_numpy(d["x"]), torch.from_numpy(d["gy"])
+    return m, x, gy, d, bool(seeded)
+
+
+def large_swin_grad_errors(d, seeded, names, grads):
+    """-> [(name, scaled max-abs error, relative-L2 error)] of parameter gradients against a LARGE_SWIN fixture."""
+    from golden_weights import SAMPLE_STRIDE
+
+    out = []
+    for n, g in zip(names, grads):
+        g = g.detach().float().cpu().reshape(-1)
+        if not seeded:
+            ref = torch.from_numpy(d["g." + n]).reshape(-1)
+        elif "gfull." + n in d:
+            ref = torch.from_numpy(d["gfull." + n]).reshape(-1)
+        else:
+            ref = torch.from_numpy(d["gsample." + n]).reshape(-1)
+            nerr = abs(float(g.double().norm()) - float(d["gnorm." + n])) / max(float(d["gnorm." + n]), 1e-12)
+            out.append((n + " (norm)", nerr, nerr))
+            g = g[::SAMPLE_STRIDE]
+        scale = max(1.0, float(ref.abs().max()))
+        out.append((n, float((g - ref).abs().max()) / scale, float((g - ref).norm() / ref.norm().clamp(min=1e-12))))
+    return out

@@ -258,5 +258,52 @@ def main():
          stride=det.stride.numpy())
 
 
+# SwinBlock cases beyond the small ones above: head_dim 192 (config 5's SwinBlock(384, 2)) and windows of
+# more than 64 tokens (ws = 14 -> 196).  Own RNG streams (numpy RandomState), so adding cases never shifts main()'s.
+LARGE_SWIN = [
+    # name, dim, heads, ws, B, H, W, seed, seeded weights (True: not stored, rebuilt from the seed by tests/golden_weights.py)
+    ("swin_d384_14x14", 384, 2, 7, 1, 14, 14, 11, True),
+    ("swin_d384_20x20", 384, 2, 7, 1, 20, 20, 12, True),
+    ("swin_d64_ws14_20x20", 64, 2, 14, 2, 20, 20, 13, False),
+    ("swin_d64_ws14_28x14", 64, 4, 14, 1, 28, 14, 14, False),
+    ("swin_d384_ws14_28x28", 384, 2, 14, 1, 28, 28, 15, True),
+]
+
+
+def swin_large_fixtures():
+    sys.path.insert(0, str(REPO / "tests"))
+    from golden_weights import grad_record, seeded_inputs, seeded_state
+
+    torch.set_num_threads(4)
+    swin = load_leaf("ref_swin", "ultralytics/nn/modules/swin_block.py")
+    for name, dim, heads, ws, B, H, W, seed, seeded in LARGE_SWIN:
+        m = swin.SwinBlock(dim, heads, ws)
+        shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+        m.load_state_dict(seeded_state(shapes, seed), strict=True)
+        x, gy = seeded_inputs(seed, (B, dim, H, W), (B, dim, H, W))
+        x.requires_grad_(True)
+        y = m(x)
+        params = list(m.parameters())
+        names = [n for n, _ in m.named_parameters()]
+        grads = torch.autograd.grad(y, [x] + params, gy)
+        arrays = dict(meta=np.array([dim, heads, ws, B, H, W, seed, int(seeded)]), y=y.detach().numpy())
+        arrays["g.x"] = grads[0].numpy()
+        for n, t in zip(names, grads[1:]):
+            if seeded:
+                for kind, v in grad_record(t).items():
+                    arrays[f"g{kind}.{n}"] = v
+            else:
+                arrays["g." + n] = t.numpy()
+        if not seeded:
+            arrays.update(sd_np(m))
+            arrays["x"] = x.detach().numpy()
+            arrays["gy"] = gy.numpy()
+        save(name, **arrays)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "swin_large":
+        swin_large_fixtures()
+    else:
+        main()
+        swin_large_fixtures()

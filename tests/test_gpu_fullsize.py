@@ -114,12 +114,15 @@ def test_fullsize_train_step_decreases_loss():
 
 @pytest.mark.parametrize("bs,sz", [(4, 320), (16, 640)])
 def test_hip_graph_step_matches_eager_and_is_isolated(bs, sz):
-    """TrainStep(graph=True) replays exactly the kernels of the eager step: same losses step by step, and eager
-    allocations made between replays must not disturb the graph's memory (regression: side-stream warm-up)."""
+    """TrainStep(graph=True) replays exactly the kernels of the eager step: the same losses step by step AND the same
+    parameters afterwards, with eager allocations, pinned-memory traffic and a second stream's work made between the
+    replays (they must not disturb the graph's memory).  Graph mode runs 3 eager warm-up steps before its first replay,
+    so replay i is eager step i + 3: 7 replays are compared with eager steps 3..9."""
     from improving_yolov8_cbam_swinblock_amd.engine.trainer import TrainStep, synthetic_batch
     from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
 
-    losses = {}
+    losses, params = {}, {}
+    probe = ("model.0.conv.weight", "model.7.attn.in_proj_weight", "model.10.sa.conv.weight", "model.22.cv2.bn.weight", "model.26.cv3.0.2.bias")
     # "split": forward + loss + backward as a graph, gradient reduction / clip / update eager (the multi-rank form)
     for mode in ("eager", "graph", "split"):
         torch.manual_seed(0)
@@ -127,24 +130,33 @@ def test_hip_graph_step_matches_eager_and_is_isolated(bs, sz):
         step = TrainStep(model, world_size=1, lr=0.01, graph={"eager": False, "graph": True, "split": "split"}[mode])
         batch = synthetic_batch(bs, sz, dev(), 1)
         out = []
-        for i in range(7):
-            if mode != "eager" and i >= 4:  # eager allocations between replays
+        for i in range(10 if mode == "eager" else 7):
+            if mode != "eager" and i >= 1:  # eager work between replays: device allocations of many sizes, pinned staging, a side stream
                 junk = [torch.full((n,), 7.0, device=dev()) for n in (1, 3, 17, 1000, 100000, 5000000)]
                 junk.append(torch.randn(1000, 1000, device=dev()).sum())
+                _ = float(junk[-1]) + float(junk[3].sum())
+                pinned = torch.arange(1000.0).pin_memory().to(dev(), non_blocking=True)
+                side = torch.cuda.Stream()
+                with torch.cuda.stream(side):
+                    junk.append(torch.ones(1 << 20, device=dev()).cumsum(0))
                 torch.cuda.synchronize()
-                del junk
+                del junk, pinned
             out.append(step(batch).float().cpu().clone())
         losses[mode] = torch.stack(out)
+        sd = model.state_dict()
+        params[mode] = {k: sd[k].detach().float().cpu().clone() for k in probe}
         del step, model
         torch.cuda.empty_cache()
-    assert torch.isfinite(losses["graph"]).all()
-    # graph mode runs 3 extra warm-up steps before its first replay: its step i is eager step i + 3... compare trend only
-    # beyond that: both must decrease and the graph's steps must continue the eager trajectory smoothly
-    assert float(losses["graph"][-1].sum()) < float(losses["graph"][0].sum())
+    assert torch.isfinite(losses["graph"]).all() and torch.isfinite(losses["split"]).all()
     assert float(losses["eager"][-1].sum()) < float(losses["eager"][0].sum())
-    # eager steps 3.. and graph steps 0.. see the same weights (identical kernels, deterministic): equal to float noise
-    torch.testing.assert_close(losses["graph"][:4], losses["eager"][3:7], rtol=2e-2, atol=2e-2)
-    torch.testing.assert_close(losses["split"][:4], losses["eager"][3:7], rtol=2e-2, atol=2e-2)
+    # identical kernels on identical weights, deterministic: equal to float noise (2e-2 covers bf16 re-association only)
+    torch.testing.assert_close(losses["graph"], losses["eager"][3:10], rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(losses["split"], losses["eager"][3:10], rtol=2e-2, atol=2e-2)
+    for mode in ("graph", "split"):  # after 10 updates each: the replicas of the three schedules still agree
+        for k in probe:
+            a, b = params[mode][k], params["eager"][k]
+            err = float((a - b).norm() / b.norm().clamp(min=1e-9))
+            assert err < 5e-3, (mode, k, err)
 
 
 def _copy_state(dst, src):

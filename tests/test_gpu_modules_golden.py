@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import GOLDEN, golden_state, load_golden
+from conftest import GOLDEN, LARGE_SWIN, golden_state, large_swin_grad_errors, load_golden, load_large_swin
 
 pytestmark = pytest.mark.gpu
 
@@ -194,6 +194,30 @@ def test_swin_block_vs_reference(name, dtype):
     for n, g in zip(names, gs):
         assert g is not None, n
         close(g, t(d["g." + n]), dict(atol=tol["atol"] * 3, rtol=0), f"{name} grad {n}")
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+@pytest.mark.parametrize("name", LARGE_SWIN)
+def test_swin_block_head_dim_192_and_large_windows_vs_reference(name, dtype):
+    """reference swin_block.py:23-58 at config 5's SwinBlock(384, 2) (head_dim 192) and with 14x14 windows (196 tokens >
+    one 64-token tile): forward, input gradient and every parameter gradient.  float32: 1e-3 (north_star); bfloat16:
+    6e-2 scaled max-abs forward, 5e-2 relative L2 on gradients."""
+    m, x, gy, d, seeded = load_large_swin(name, lambda dim, heads, ws: P().SwinBlock(dim, heads, ws))
+    m = m.to(dev())
+    x = x.to(dev()).requires_grad_(True)
+    y = run(m, x, dtype)
+    tol = F32_TOL if dtype == torch.float32 else BF16_TOL
+    close(y, t(d["y"]), tol, f"{name} fwd")
+    gs = grads_of(y, [x] + list(m.parameters()), gy.to(dev()))
+    if dtype == torch.float32:
+        close(gs[0], t(d["g.x"]), dict(atol=3e-3, rtol=0), f"{name} grad x")
+    else:
+        close_l2(gs[0], t(d["g.x"]), 5e-2, f"{name} grad x")
+    for n, emax, erel in large_swin_grad_errors(d, seeded, [k for k, _ in m.named_parameters()], gs[1:]):
+        if dtype == torch.float32:
+            assert emax <= 3e-3 or erel <= 1e-3, (n, emax, erel)
+        else:
+            assert erel <= 5e-2 or emax <= 2e-2, (n, emax, erel)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
