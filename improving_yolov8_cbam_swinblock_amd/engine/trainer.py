@@ -1,6 +1,6 @@
 """Training step of the hot path (reference: ultralytics/engine/trainer.py:383-399,614-622,788-849 and
 models/yolo/detect/train.py:90-115), reduced to what the benchmark step needs: bf16 autocast forward,
-v8 detection loss, backward (+ RCCL gradient mean), gradient clip 10.0, SGD-nesterov step."""
+v8 detection loss, backward (+ RCCL gradient mean), gradient clip 10.0, SGD-nesterov step, EMA update."""
 import os
 
 import torch
@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from .. import ops
 from .ddp import GradientBuckets
+from .optim import FusedSGD, ModelEMA
 
 # weight-gradient GEMMs on a second stream during backward (ops.async_wgrad) in EAGER steps; YMI_WGRAD_STREAM=0 keeps
 # one stream.  Graph-replayed steps stay single-stream: measured no wall-time gain there, and concurrent kernels stretch
@@ -15,27 +16,10 @@ from .ddp import GradientBuckets
 ASYNC_WGRAD = os.environ.get("YMI_WGRAD_STREAM", "1") != "0"
 
 
-def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
-    """parameter groups of reference build_optimizer (trainer.py:788-849): weights with decay, BN/LN weights and
-    all biases without; SGD with nesterov momentum (the 'SGD' branch, trainer.py:832-833)."""
-    g_w, g_n, g_b = [], [], []
-    norm = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
-    for mod_name, mod in model.named_modules():
-        for pn, p in mod.named_parameters(recurse=False):
-            if not p.requires_grad:
-                continue
-            if "bias" in pn:
-                g_b.append(p)
-            elif isinstance(mod, norm):
-                g_n.append(p)
-            else:
-                g_w.append(p)
-    # fused multi-tensor update on the GPU (one kernel per parameter group instead of a chain of foreach passes)
-    fused = bool(g_b) and g_b[0].is_cuda and os.environ.get("YMI_FUSED_SGD", "1") != "0"
-    opt = torch.optim.SGD(g_b, lr=lr, momentum=momentum, nesterov=True, fused=True if fused else None)  # None: foreach
-    opt.add_param_group({"params": g_w, "weight_decay": decay})
-    opt.add_param_group({"params": g_n, "weight_decay": 0.0})
-    return opt
+def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, ema=None, world_size=1):
+    """reference build_optimizer (trainer.py:788-849, 'SGD' branch :832-833) + optimizer_step's clip (:617): three
+    parameter groups, nesterov momentum, weight decay on the weights only - as the fused HIP step (engine/optim.py)."""
+    return FusedSGD(model, lr=lr, momentum=momentum, decay=decay, nesterov=True, max_norm=10.0, ema=ema, world_size=1)
 
 
 def synthetic_batch(batch, imgsz, device, seed, boxes_per_image=4):
@@ -56,19 +40,29 @@ def synthetic_batch(batch, imgsz, device, seed, boxes_per_image=4):
 
 class TrainStep:
     """one optimisation step: forward under autocast, loss.sum() * world (reference trainer.py:386-388), backward
-    with bucketed RCCL mean, unscale-free clip (bf16 needs no GradScaler), optimizer step, zero_grad.
+    with bucketed RCCL mean, then the reference's optimizer_step (trainer.py:614-622) as the fused HIP step: global-norm
+    clip 10.0 (bf16 needs no GradScaler), SGD-nesterov over the three parameter groups, EMA update; zero_grad.
 
     graph=True replays the step as a HIP graph (every kernel of libyolo_mi355 only enqueues on the stream it is
     given, so the capture is legal; needs static shapes: batch["max_boxes"] must be set):
-      * one rank: the whole step (forward, loss, backward, clip, update) is one graph;
-      * several ranks: forward + loss + backward are one graph; the RCCL gradient mean, the clip and the update run
-        eagerly after the replay (a dozen launches), because RCCL calls are not captured."""
+      * one rank: the whole step (forward, loss, backward, clip, update, EMA) is one graph;
+      * several ranks: forward + loss + backward are one graph; the RCCL gradient mean and the fused update run eagerly
+        after the replay (half a dozen launches), because RCCL calls are not captured.
+    Learning rates / momentum changed through `opt.param_groups` reach a replayed graph: they are read from a device
+    array (`FusedSGD.sync_hyper`).
 
-    def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20, graph=False):
+    What must NOT be inside a captured region (found in round 2, tools/graph_cat_probe.py): torch.cat / torch.stack -
+    and therefore torch.nn.utils.clip_grad_norm_.  On this ROCm build ATen's cat stages its tensor metadata through a
+    host buffer that a memcpy NODE copies to the device; a replay copies whatever that host buffer holds by then (any
+    later eager cat/stack rewrites it), so the replayed cat reads wrong pointers: silently wrong values, or a memory
+    fault.  The captured step contains only kernels of this library and elementwise ATen ops."""
+
+    def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20, graph=False, ema=True):
         self.model = model
         self.world = world_size
         self.dtype = dtype
-        self.opt = build_optimizer(model, lr=lr)
+        self.ema = ModelEMA(model) if ema is True else (ema or None)
+        self.opt = build_optimizer(model, lr=lr, ema=self.ema)
         self.use_graph = bool(graph)
         self.full_graph = self.use_graph and world_size == 1 and graph != "split"  # graph="split": the multi-rank form on one rank
         self.buckets = GradientBuckets(model, world_size, bucket_bytes, overlap=not self.use_graph)
@@ -86,11 +80,7 @@ class TrainStep:
                 raise ValueError("graph=True needs batch['max_boxes'] (static target shape)")
             # The first batch's tensors become the graph's static inputs (later batches are copied into them).
             self._static = dict(batch)
-            # Warm-up (allocator, lazy state, workspaces) on the CURRENT stream.  Measured on ROCm 7.0 / torch 2.10:
-            # warming up on a side stream, as the CUDA recipe suggests, left the caching allocator handing the
-            # graph's private-pool blocks to later eager allocations (corrupted replays at bs >= 16); with the
-            # warm-up on the current stream replays stay isolated (tools/graph_probe.py).
-            for _ in range(3):
+            for _ in range(3):  # warm-up: allocator, lazy state (weight arena, optimizer tables), workspaces
                 self.eager_step(self._static)
             torch.cuda.synchronize()
             self._graph = torch.cuda.CUDAGraph()
@@ -104,6 +94,8 @@ class TrainStep:
                     self._static_items = self._forward_backward(self._static)
             if not self.full_graph:  # the gradients the replays rewrite in place
                 self._graph_grads = {p: p.grad for p in self.params if p.grad is not None}
+            elif self.ema is not None:
+                self.ema.updates -= 1  # the capture recorded the update without running it
         else:
             for k, v in batch.items():
                 if torch.is_tensor(v) and v is not self._static[k]:
@@ -112,8 +104,13 @@ class TrainStep:
                     self._static[k].copy_(v)
                 elif not torch.is_tensor(v) and v != self._static[k]:
                     raise ValueError(f"graph=True: batch['{k}'] = {v!r} differs from the captured value {self._static[k]!r}")
+        if self.full_graph:
+            self.opt.sync_hyper()  # scheduler changes reach the captured update through the device array
         self._graph.replay()
-        if not self.full_graph:
+        if self.full_graph:
+            if self.ema is not None:
+                self.ema.updates += 1  # the captured step advanced the device counter
+        else:
             self._reduce_and_update(self._graph_grads)
             self.opt.zero_grad(set_to_none=True)  # drops references only: the graph owns its gradient buffers
         return self._static_items
@@ -128,12 +125,8 @@ class TrainStep:
         return items
 
     def _reduce_and_update(self, grads_of=None):
-        if grads_of is not None and self.world == 1:  # (single-rank use of the split path: tests)
-            for p, g in grads_of.items():
-                p.grad = g
-        self.buckets.finish(grads_of)
-        torch.nn.utils.clip_grad_norm_(self.params, max_norm=10.0)
-        self.opt.step()
+        self.buckets.finish(grads_of)  # world > 1: leaves the mean in .grad (views of the flat buckets)
+        self.opt.step(grads_of if self.world == 1 else None)
 
     def eager_step(self, batch):
         items = self._forward_backward(batch)

@@ -233,6 +233,41 @@ int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor
 int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const void* state,
                         size_t state_bytes, const float* grad_loss, const ymi_tensor* dbox_maps, const ymi_tensor* dcls_maps, void* stream);
 
+/* ------------------------------------------------------------------------- optimizer step ---- */
+/* The update either side of backward, reference engine/trainer.py:614-622 (optimizer_step: clip_grad_norm_(10.0),
+ * SGD-nesterov step, EMA update), :788-849 (three parameter groups) and utils/torch_utils.py:657-673 (ModelEMA.update),
+ * as multi-tensor launches over a DEVICE table of every tensor (built once: parameters, momentum and EMA buffers do not
+ * move).  Gradient tensors move from step to step in eager mode, so their device addresses are passed as a HOST array
+ * and travel in the kernel arguments (graph-capturable, no staging buffer).
+ *   table      [n] ymi_opt_entry; group: 0 biases, 1 decayed weights, 2 norm weights (index into hyper's lr / wd);
+ *              momentum / ema may be NULL (no momentum buffer: EMA-only entry; no ema: EMA not attached)
+ *   chunk_map  [n_chunks][2] int32 (tensor index, chunk index): one workgroup per ymi_opt_chunk_elems() elements
+ *   hyper      [12] float on the device: lr[3], weight_decay[3], momentum, max_norm (<= 0: no clipping), ema decay,
+ *              ema tau, nesterov (0/1), gradient scale (1 / world size)
+ *   state      32 bytes on the device: float clip, float total_norm, float ema_d, float 1-ema_d, int64 updates
+ * A launch covers tensors [first_tensor, first_tensor + n_tensors), n_tensors <= YMI_OPT_MAX_GRADS, whose chunks are the
+ * n_chunks entries at chunk_map; host_grads[i] is the gradient of tensor first_tensor + i or NULL (no gradient this step). */
+#define YMI_OPT_MAX_GRADS 448
+typedef struct ymi_opt_entry {
+    float* param;
+    float* momentum;
+    float* ema;
+    int64_t numel;
+    int32_t group;
+    int32_t _pad;
+} ymi_opt_entry;
+int64_t ymi_opt_chunk_elems(void);
+/* partial sums of squares of (gradient * scale) into partials[partials_offset ..]; finalize != 0 (last launch of a step):
+ * fixed-order sum of all partials_total partials -> state.total_norm, state.clip = min(1, max_norm / (norm + 1e-6)),
+ * state.updates += 1, state.ema_d = decay * (1 - exp(-updates / tau)). */
+int ymi_opt_grad_norm(const ymi_opt_entry* table, const int32_t* chunk_map, int32_t first_tensor, int32_t n_tensors, int64_t n_chunks,
+                      const float* const* host_grads, const float* hyper, float* partials, int64_t partials_offset, int64_t partials_total,
+                      void* state, int32_t finalize, void* stream);
+/* g = grad*scale*clip (+ wd*p); buf = momentum*buf + g; g = nesterov ? g + momentum*buf : buf; p -= lr*g;
+ * ema = d*ema + (1-d)*p.  host_grads == NULL: EMA-only pass over the given tensors (buffers, frozen parameters). */
+int ymi_opt_update(const ymi_opt_entry* table, const int32_t* chunk_map, int32_t first_tensor, int32_t n_tensors, int64_t n_chunks,
+                   const float* const* host_grads, const float* hyper, const void* state, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -301,9 +301,68 @@ def swin_large_fixtures():
         save(name, **arrays)
 
 
+def opt_step_fixture():
+    """two optimizer steps of the REAL reference trainer code on the width-reduced model of e2e_tiny: BaseTrainer.build_optimizer
+    ('SGD' branch, trainer.py:788-849), optimizer_step's clip + step + zero_grad (trainer.py:614-622, GradScaler disabled as
+    for fp32 / bf16) and ModelEMA.update (torch_utils.py:657-673).  Stored: group membership, gradient norms, and strided
+    samples + norms of every parameter / EMA entry after each step (the model's initial weights are e2e_tiny's)."""
+    sys.path.insert(0, str(REPO / "tests"))
+    from golden_weights import grad_record
+
+    tasks = import_reference_package()
+    from ultralytics.engine.trainer import BaseTrainer
+    from ultralytics.utils.loss import v8DetectionLoss
+    from ultralytics.utils.torch_utils import ModelEMA
+
+    torch.set_num_threads(4)
+    d = json.loads((OUT / "e2e_tiny_seed7_yaml.json").read_text())
+    z = np.load(OUT / "e2e_tiny_seed7.npz")
+    torch.manual_seed(7)
+    model = tasks.DetectionModel(d, ch=3, nc=1, verbose=False)
+    model.load_state_dict({k[2:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("w.")}, strict=True)
+    model.args = SimpleNamespace(box=7.5, cls=0.5, dfl=1.5)
+    for k, v in model.named_parameters():  # trainer.py:244-256: '.dfl' is always frozen
+        if ".dfl" in k:
+            v.requires_grad = False
+    fake = SimpleNamespace(args=SimpleNamespace(lr0=0.01, momentum=0.937, warmup_bias_lr=0.1), data={"nc": 1})
+    opt = BaseTrainer.build_optimizer(fake, model, name="SGD", lr=0.01, momentum=0.937, decay=5e-4)
+    ema = ModelEMA(model)
+    batch = {"img": torch.from_numpy(z["img"]), "batch_idx": torch.from_numpy(z["batch_idx"]), "cls": torch.from_numpy(z["cls"]),
+             "bboxes": torch.from_numpy(z["bboxes"])}
+    names = {id(p): n for n, p in model.named_parameters()}
+    arrays = {}
+    meta = {"groups": [[names[id(p)] for p in g["params"]] for g in opt.param_groups],
+            "group_hyper": [{k: g[k] for k in ("lr", "momentum", "weight_decay", "nesterov")} for g in opt.param_groups], "norms": [], "loss": []}
+    model.train()
+    crit = v8DetectionLoss(model)
+    for step in range(2):
+        loss, items = crit(model(batch["img"]), batch)
+        loss.sum().backward()
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10.0)  # trainer.py:617
+        opt.step()
+        opt.zero_grad()
+        ema.update(model)
+        meta["norms"].append(float(norm))
+        meta["loss"].append([float(v) for v in loss])
+        for n, p in model.state_dict().items():
+            if p.dtype.is_floating_point:
+                for kind, v in grad_record(p).items():
+                    arrays[f"s{step}.p{kind}.{n}"] = v
+        for n, p in ema.ema.state_dict().items():
+            if p.dtype.is_floating_point:
+                for kind, v in grad_record(p).items():
+                    arrays[f"s{step}.e{kind}.{n}"] = v
+    meta["ema_updates"] = ema.updates
+    save("opt_step_tiny", **arrays)
+    (OUT / "opt_step_tiny.json").write_text(json.dumps(meta))
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "swin_large":
         swin_large_fixtures()
+    elif len(sys.argv) > 1 and sys.argv[1] == "opt_step":
+        opt_step_fixture()
     else:
         main()
         swin_large_fixtures()
+        opt_step_fixture()

@@ -94,7 +94,7 @@ def _noise_floor(name, ref_grads):
     return name.endswith("mlp.2.bias")
 
 
-def _teacher_forced(oracle, model, rec, dtype, tol_fwd, tol_grad, loose=()):
+def _teacher_forced(oracle, model, rec, dtype, tol_fwd, tol_grad, loose=None):
     """every top-level layer alone, on the oracle's input and output gradient.  loose: {layer type: bound} overrides."""
     worst = []
     for om, gm in zip(oracle.model, model.model):
@@ -114,7 +114,7 @@ def _teacher_forced(oracle, model, rec, dtype, tol_fwd, tol_grad, loose=()):
         yg = list(yg) if isinstance(yg, (list, tuple)) else [yg]
         torch.autograd.backward(yg, [(g if g is not None else torch.zeros_like(y)).to(dev()).to(y.dtype) for y, g in zip(yg, r["gy"])])
         kind = type(gm).__name__
-        tf, tg = loose.get(kind, (tol_fwd, tol_grad))
+        tf, tg = (loose or {}).get(kind, (tol_fwd, tol_grad))
         for k, (a, b) in enumerate(zip(yg, yo)):
             e = rel_l2(a, b)
             worst.append((f"layer {om.i} {kind} out{k}", e, tf))
