@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W
 
 One step = forward (bf16 autocast) + v8 detection loss + backward (+ RCCL gradient mean over ranks) + grad-clip +
-SGD-nesterov update on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
+SGD-nesterov update + EMA on one synthetic batch already resident in HBM.  Rank 0 prints ONE JSON line.
   roofline      measured live: HIP events on the launch stream around every launch of the MFMA GEMM kernels
                 (algorithmic FLOP / elapsed);
   forward       north_star's target number: the train-mode forward alone (graph-replayed), ms and MFMA fraction;
@@ -305,7 +305,7 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.model} (CBAM + 2x SwinBlock + SPPF5 + SPPF7, nc=1) forward + v8 loss + backward + clip + SGD-nesterov step, bs={args.batch}/GPU {args.imgsz}x{args.imgsz}",
+                "workload": f"{args.model} (CBAM + 2x SwinBlock + SPPF5 + SPPF7, nc=1) forward + v8 loss + backward + clip + SGD-nesterov + EMA step, bs={args.batch}/GPU {args.imgsz}x{args.imgsz}",
                 "global_batch": args.batch * args.gpus,
                 "imgsz": args.imgsz,
                 "parallelism": f"dp{args.gpus}",

@@ -156,6 +156,7 @@ class FusedSGD:
         if self.ema is not None and self.ema.updates:
             self._state.view(torch.int64)[2] = int(self.ema.updates)
         self._hyper = torch.zeros(12, dtype=torch.float32, device=dev)
+        self._hyper_host = None  # a fresh device array: the next sync_hyper() must fill it
         self._ptrs = [p.data_ptr() for p, *_ in entries]
 
     def _stale(self):
