@@ -240,6 +240,32 @@ __global__ __launch_bounds__(256) void decode_kernel(LossGeom g, float* __restri
     }
 }
 
+// ---- inference decode: Detect._inference (head.py:103-142, non-export branch) ---------------------------------
+// y[b][0:4][a] = dist2bbox(DFL(box), anchor, xywh=True) * stride ; y[b][4+c][a] = sigmoid(cls[c]).  Output is the
+// reference's [B, 4+nc, A] float32 tensor (anchor index fastest).  Four lanes per anchor as in decode_kernel; the quad
+// then walks the classes.  A-major stores: the 64 lanes of a wave cover 16 consecutive anchors of 4 rows each.
+template <typename T>
+__global__ __launch_bounds__(256) void infer_decode_kernel(LossGeom g, float* __restrict__ y) {
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t quad = t >> 2;
+    const int side = (int)(t & 3);
+    const bool live = quad < (int64_t)g.B * g.A;
+    const int b = live ? (int)(quad / g.A) : 0, a = live ? (int)(quad - (int64_t)b * g.A) : 0;
+    const Anchor an = anchor_of(g, b, a);
+    float x[REG], p[REG], lse;
+    load16<T>(reinterpret_cast<const T*>(pick(g.box, an.l)) + an.pix * pick(g.ldb, an.l) + side * REG, x);
+    const float e = softmax_expect(x, p, &lse);
+    float d[4];
+    quad_gather(e, d);
+    if (!live) return;
+    float* yo = y + (int64_t)b * (4 + g.nc) * g.A + a;
+    const float x1 = an.ax - d[0], y1 = an.ay - d[1], x2 = an.ax + d[2], y2 = an.ay + d[3];
+    const float box[4] = {(x1 + x2) * 0.5f * an.s, (y1 + y2) * 0.5f * an.s, (x2 - x1) * an.s, (y2 - y1) * an.s};
+    yo[(int64_t)side * g.A] = side == 0 ? box[0] : side == 1 ? box[1] : side == 2 ? box[2] : box[3];
+    const T* cp = reinterpret_cast<const T*>(pick(g.cls, an.l)) + an.pix * pick(g.ldc, an.l);
+    for (int c = side; c < g.nc; c += 4) yo[(int64_t)(4 + c) * g.A] = 1.0f / (1.0f + expf(-to_f32(cp[c])));
+}
+
 // ---- K2: alignment metric and overlaps for every (image, gt, anchor) (tal.py:118-160) -------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void metric_kernel(LossGeom g, const float* __restrict__ targets, const float* __restrict__ pb,
@@ -695,5 +721,18 @@ extern "C" int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const
     else
         hipLaunchKernelGGL((loss_kernel<float, true>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, grad_loss, nullptr);
     YMI_CHECK_LAUNCH("detect_loss_bwd");
+    return YMI_OK;
+}
+
+extern "C" int ymi_detect_decode(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, float* y, void* stream) {
+    LossGeom g;
+    int rc = fill_geom(g, nl, box_maps, cls_maps, strides, 1, "detect_decode");
+    if (rc) return rc;
+    YMI_CHECK_ARG(y, "detect_decode: null output");
+    const int64_t BA = (int64_t)g.B * g.A;
+    const unsigned qblocks = (unsigned)((BA * 4 + 255) / 256);
+    if (box_maps[0].dtype == YMI_BF16) hipLaunchKernelGGL(infer_decode_kernel<bf16_t>, dim3(qblocks), dim3(256), 0, (hipStream_t)stream, g, y);
+    else hipLaunchKernelGGL(infer_decode_kernel<float>, dim3(qblocks), dim3(256), 0, (hipStream_t)stream, g, y);
+    YMI_CHECK_LAUNCH("detect_decode");
     return YMI_OK;
 }

@@ -34,13 +34,36 @@ def setup(backend=None):
     return rank, local, world
 
 
-def broadcast_parameters(module, src=0):
-    """same initial weights and buffers on every rank (what DDP's constructor does, trainer.py:278)."""
+def broadcast_parameters(module, src=0, bucket_bytes=64 << 20):
+    """same initial weights and buffers on every rank (what DDP's constructor does, trainer.py:278): the tensors are
+    packed into a few flat buffers per dtype (one multi-tensor copy in, one out), so the exchange is a handful of large
+    broadcasts - xGMI is point-to-point, 141 small messages would each pay the link latency."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return
-    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers() if b.dtype.is_floating_point]
+    tensors = [p.data for p in module.parameters()] + [b.data for b in module.buffers()]
+    by_dtype = {}
     for t in tensors:
-        dist.broadcast(t, src)
+        by_dtype.setdefault(t.dtype, []).append(t)
+    for dt, group in by_dtype.items():
+        cur, size = [], 0
+        chunks = []
+        for t in group:
+            cur.append(t)
+            size += t.numel() * t.element_size()
+            if size >= bucket_bytes:
+                chunks.append(cur)
+                cur, size = [], 0
+        if cur:
+            chunks.append(cur)
+        for chunk in chunks:
+            flat = torch.empty(sum(t.numel() for t in chunk), dtype=dt, device=chunk[0].device)
+            views, off = [], 0
+            for t in chunk:
+                views.append(flat[off : off + t.numel()].view_as(t))
+                off += t.numel()
+            torch._foreach_copy_(views, chunk)
+            dist.broadcast(flat, src)
+            torch._foreach_copy_(chunk, views)
 
 
 class GradientBuckets:

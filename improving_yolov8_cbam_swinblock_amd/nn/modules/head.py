@@ -87,15 +87,16 @@ class Detect(nn.Module):
         return box, cls
 
     def _inference(self, x):
-        """reference head.py:103-142, non-export branch (decode of [B, no, 8400]: small torch ops)."""
-        shape = x[0].shape
-        x_cat = torch.cat([xi.float().reshape(shape[0], self.no, -1) for xi in x], 2)
-        if self.dynamic or self.shape != shape:
-            self.anchors, self.strides = (t.transpose(0, 1) for t in make_anchors(x, self.stride, 0.5))
-            self.shape = shape
-        box, cls = x_cat.split((self.reg_max * 4, self.nc), 1)
-        dbox = dist2bbox(self.dfl(box), self.anchors.unsqueeze(0), xywh=True, dim=1) * self.strides
-        return torch.cat((dbox, cls.sigmoid()), 1)
+        """reference head.py:103-142, non-export branch: DFL expectation, anchor decode, stride scale and class sigmoid in
+        one HIP launch over the Detect maps (csrc/loss.hip infer_decode_kernel) -> [B, 4+nc, A] float32."""
+        if self.reg_max != 16:
+            raise NotImplementedError("the decode kernel is built for reg_max = 16")
+        box = [xi[:, : self.reg_max * 4] for xi in x]
+        cls = [xi[:, self.reg_max * 4 :] for xi in x]
+        self.shape = x[0].shape
+        if getattr(self, "_stride_host", None) is None or len(self._stride_host) != self.nl:
+            self._stride_host = [float(s) for s in self.stride]  # one device->host read, not one per call
+        return ops.detect_decode(box, cls, self._stride_host)
 
     def bias_init(self):
         """reference head.py:144-155."""

@@ -191,11 +191,18 @@ class BaseModel(nn.Module):
         return self
 
     def load(self, weights, verbose=False):
-        """load a state_dict or a module's weights by intersecting keys (reference tasks.py:284-297)."""
-        model = weights["model"] if isinstance(weights, dict) and "model" in weights else weights
-        csd = model if isinstance(model, dict) else model.float().state_dict()
+        """load weights by intersecting keys and shapes (reference tasks.py:284-297).  `weights`: a state_dict, a module,
+        a checkpoint dict in the reference's layout (utils/checkpoint.py) or a path to one (read with weights_only=True)."""
+        from ..utils.checkpoint import load_checkpoint, state_dict_of
+
+        if isinstance(weights, (str, bytes)) or hasattr(weights, "__fspath__"):
+            csd, _ = load_checkpoint(weights)
+        else:
+            csd = state_dict_of(weights)
+        csd = {k: v.float() if v.dtype.is_floating_point else v for k, v in csd.items()}
         csd = intersect_dicts(csd, self.state_dict())
         self.load_state_dict(csd, strict=False)
+        self._arena = None
         return len(csd)
 
     def loss(self, batch, preds=None):

@@ -896,3 +896,15 @@ class _DetectLoss(torch.autograd.Function):
 
 def detect_loss(box_maps, cls_maps, strides, targets, topk=10, alpha=0.5, beta=6.0):
     return _DetectLoss.apply(targets, tuple(strides), topk, alpha, beta, *box_maps, *cls_maps)
+
+
+def detect_decode(box_maps, cls_maps, strides):
+    """Detect._inference of reference head.py:103-142 on the per-level maps -> [B, 4+nc, A] float32 (no gradient)."""
+    nl = len(box_maps)
+    b = box_maps[0].shape[0]
+    nc = cls_maps[0].shape[1]
+    anchors = sum(int(t.shape[2] * t.shape[3]) for t in box_maps)
+    y = torch.empty((b, 4 + nc, anchors), dtype=torch.float32, device=box_maps[0].device)
+    st = (ctypes.c_float * nl)(*[float(s) for s in strides])
+    check(L().ymi_detect_decode(nl, _map_array([t.detach() for t in box_maps]), _map_array([t.detach() for t in cls_maps]), st, ptr(y), stream_ptr()), "detect_decode")
+    return y

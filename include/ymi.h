@@ -233,6 +233,12 @@ int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor
 int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const void* state,
                         size_t state_bytes, const float* grad_loss, const ymi_tensor* dbox_maps, const ymi_tensor* dcls_maps, void* stream);
 
+/* Detect._inference (nn/modules/head.py:103-142, non-export branch; DFL nn/modules/block.py:58-77; make_anchors /
+ * dist2bbox utils/tal.py:364-388): per level l a box map [B,H,W,64] and a class map [B,H,W,nc] (NHWC, channel slices of
+ * the concatenated Detect output are fine) -> y [B][4+nc][A] float32: rows 0..3 = (cx, cy, w, h) in pixels, rows 4.. =
+ * sigmoid(class logits); anchors in the reference's order (level, y, x), centre offset 0.5. */
+int ymi_detect_decode(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, float* y, void* stream);
+
 /* ------------------------------------------------------------------------- optimizer step ---- */
 /* The update either side of backward, reference engine/trainer.py:614-622 (optimizer_step: clip_grad_norm_(10.0),
  * SGD-nesterov step, EMA update), :788-849 (three parameter groups) and utils/torch_utils.py:657-673 (ModelEMA.update),

@@ -314,3 +314,17 @@ def test_two_rank_training_keeps_replicas_identical(graph):
     assert np.isfinite(res[0][1]).all() and np.isfinite(res[1][1]).all()
     assert not np.allclose(res[0][1], res[1][1])  # different shards
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)
+
+
+def test_profile_table_lists_every_layer():
+    """utils/profile.py: the per-module forward / backward table (reference torch_utils.py:792-870 reporting format)."""
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+    from improving_yolov8_cbam_swinblock_amd.utils.profile import profile_model
+
+    torch.manual_seed(0)
+    model = DetectionModel("yolov8s.yaml", ch=3, nc=1).to(dev())
+    rows = profile_model(model, torch.rand(2, 3, 320, 320, device=dev()), n=2, verbose=False)
+    assert [r[0] for r in rows] == list(range(27))
+    assert [r[1] for r in rows][:3] == ["Conv", "Conv", "C2f"] and rows[-1][1] == "Detect"
+    assert all(r[4] > 0 for r in rows) and sum(r[2] for r in rows) == 13405269
+    assert all(r[5] > 0 for r in rows if r[1] in ("Conv", "C2f", "SPPF", "CBAM", "SwinBlock", "Detect"))

@@ -140,7 +140,12 @@ def _worker(rank, world, port, q):
 
     torch.manual_seed(100 + rank)
     lin = torch.nn.Linear(5, 3)
-    broadcast_parameters(lin)
+    bn = torch.nn.BatchNorm1d(3)  # float buffers + an int64 counter: every dtype travels
+    bn.running_mean.fill_(float(rank + 1))
+    bn.num_batches_tracked.fill_(7 * (rank + 1))
+    both = torch.nn.Sequential(lin, bn)
+    broadcast_parameters(both, bucket_bytes=16)  # several flat chunks per dtype
+    assert float(bn.running_mean[0]) == 1.0 and int(bn.num_batches_tracked) == 7, "buffers must come from rank 0"
     w0 = lin.weight.detach().clone()
     torch.manual_seed(shard_seed(1, rank))
     x = torch.randn(4, 5)
@@ -174,3 +179,39 @@ def test_ddp_gradient_allreduce_gloo_world2():
     assert not np.allclose(res[0][2], res[1][2])  # different shards -> different local gradients
     for r in res:
         np.testing.assert_allclose(r[3], mean, rtol=1e-6, atol=1e-7)
+
+
+def test_checkpoint_layout_and_weights_only_round_trip(tmp_path):
+    """utils/checkpoint.py writes the reference's checkpoint keys (trainer.py:536-552) with plain containers in the
+    weight slots, reads them back with weights_only=True, accepts a bare reference-style state_dict, and refuses a
+    pickled-module checkpoint with an explanation instead of executing it."""
+    import torch.nn as nn
+
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+    from improving_yolov8_cbam_swinblock_amd.utils.checkpoint import load_checkpoint, save_checkpoint
+
+    torch.manual_seed(3)
+    model = DetectionModel("yolov8n-cbam.yaml", ch=3, nc=1)
+    f = tmp_path / "last.pt"
+    ckpt = save_checkpoint(f, model, epoch=7, best_fitness=0.5, train_args={"imgsz": 640})
+    assert set(ckpt) >= {"epoch", "best_fitness", "model", "ema", "updates", "optimizer", "train_args", "train_metrics", "train_results", "date", "version", "license", "docs"}
+    sd, back = load_checkpoint(f)
+    assert back["epoch"] == 7 and back["train_args"]["imgsz"] == 640 and back["ema"] is None
+    ref = model.state_dict()
+    assert list(sd) == list(ref)
+    for k, v in sd.items():  # stored as fp16 like the reference's EMA
+        assert v.dtype == (torch.float16 if ref[k].dtype.is_floating_point else ref[k].dtype)
+        assert torch.allclose(v.float(), ref[k].float(), rtol=1e-3, atol=1e-4)
+    other = DetectionModel("yolov8n-cbam.yaml", ch=3, nc=1)
+    assert other.load(f) == len(ref)
+    assert torch.allclose(other.model[0].conv.weight, model.model[0].conv.weight.half().float())
+    # a bare state_dict file (what the reference's `model.state_dict()` gives)
+    g = tmp_path / "sd.pt"
+    torch.save(model.state_dict(), g)
+    assert other.load(g) == len(ref)
+    assert torch.equal(other.model[0].conv.weight, model.model[0].conv.weight)
+    # a pickled module (the reference's own format) is refused, not executed
+    h = tmp_path / "pickled.pt"
+    torch.save({"epoch": 0, "model": nn.Linear(2, 2), "ema": None}, h)
+    with pytest.raises(RuntimeError, match="weights_only"):
+        load_checkpoint(h)
