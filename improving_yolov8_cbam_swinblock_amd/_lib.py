@@ -53,6 +53,7 @@ _SIGNATURES = {
     "ymi_copy": (_c_i32, [_TP, _TP, _vp]),
     "ymi_upsample2x": (_c_i32, [_TP, _TP, _vp]),
     "ymi_upsample2x_bwd": (_c_i32, [_TP, _TP, _vp]),
+    "ymi_upsample2x_bwd_acc": (_c_i32, [_TP, _TP, _vp]),
     "ymi_add_inplace": (_c_i32, [_TP, _TP, _vp]),
     "ymi_pack_conv_weight_fwd": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _vp, _vp]),
     "ymi_pack_conv_weight_dgrad": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _c_i32, _vp, _vp]),
@@ -70,6 +71,7 @@ _SIGNATURES = {
     ),
     "ymi_bn_act_bwd": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_data": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
+    "ymi_conv2d_bwd_data_add": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp]),
     "ymi_conv2d_bwd_weight": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_weight_workspace": (_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "ymi_sppf_pool3_fwd": (_c_i32, [_TP, _c_i64, _TP, _TP, _TP, _vp]),
@@ -82,6 +84,7 @@ _SIGNATURES = {
     "ymi_window_reverse": (_c_i32, [_TP, _c_i64, _TP, _vp]),
     "ymi_layernorm_fwd": (_c_i32, [_TP, _c_i64, _vp, _vp, _c_f32, _TP, _vp, _vp, _vp]),
     "ymi_layernorm_bwd": (_c_i32, [_TP, _c_i64, _TP, _vp, _vp, _vp, _TP, _c_i32, _vp, _vp, _vp, _sz, _vp]),
+    "ymi_layernorm_bwd_add": (_c_i32, [_TP, _c_i64, _TP, _vp, _vp, _vp, _TP, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_window_attention_fwd": (_c_i32, [_TP, _c_i64, _c_i64, _TP, _vp, _vp]),
     "ymi_window_attention_bwd": (_c_i32, [_TP, _TP, _TP, _vp, _c_i64, _c_i64, _TP, _vp]),
     "ymi_colsum": (_c_i32, [_TP, _vp, _vp, _sz, _vp]),

@@ -96,7 +96,7 @@ extern "C" int ymi_nhwc_to_nchw(const ymi_tensor* src, float* dst, void* stream)
 }
 
 // ------------------------------------------------------------------- copy / upsample / accumulate
-// MODE 0: dst = src ; 1: dst(2h+i,2w+j) = src(h,w) ; 2: dst(h,w) = sum src(2h+i,2w+j) ; 3: dst += src
+// MODE 0: dst = src ; 1: dst(2h+i,2w+j) = src(h,w) ; 2: dst(h,w) = sum src(2h+i,2w+j) ; 3: dst += src ; 4: dst(h,w) += sum src(2h+i,2w+j)
 template <typename TS, typename TD, int MODE, bool VEC>
 __global__ void move_kernel(TV s, TV d) {
     constexpr int G = VEC ? 4 : 1;
@@ -111,7 +111,7 @@ __global__ void move_kernel(TV s, TV d) {
         const int g = (int)(i - pu * ugroups);
         const int64_t p = pu;
         int w = 0, h = 0, n = 0;
-        if (MODE == 1 || MODE == 2) {
+        if (MODE == 1 || MODE == 2 || MODE == 4) {
             const uint32_t t = pu / uw;
             w = (int)(pu - t * uw);
             n = (int)(t / uh);
@@ -133,7 +133,7 @@ __global__ void move_kernel(TV s, TV d) {
 #pragma unroll
             for (int r = 0; r < G; ++r) v[r] = (a[r] + b[r]) + (c2[r] + e[r]);
         }
-        if (MODE == 3) {
+        if (MODE == 3 || MODE == 4) {
             float o[G];
             if constexpr (VEC) Pack<TD, 4>::load(dst + p * d.ld + g * 4, o);
             else o[0] = to_f32(dst[p * d.ld + g]);
@@ -178,6 +178,11 @@ extern "C" int ymi_upsample2x_bwd(const ymi_tensor* src, const ymi_tensor* dst, 
     YMI_CHECK_ARG(ymi_tensor_ok(src) && ymi_tensor_ok(dst), "upsample2x_bwd: bad tensor");
     YMI_CHECK_ARG(dst->n == src->n && src->h == 2 * dst->h && src->w == 2 * dst->w && dst->c == src->c, "upsample2x_bwd: shapes");
     return launch_move<2>(src, dst, "upsample2x_bwd", (hipStream_t)stream);
+}
+extern "C" int ymi_upsample2x_bwd_acc(const ymi_tensor* src, const ymi_tensor* dst, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(src) && ymi_tensor_ok(dst), "upsample2x_bwd_acc: bad tensor");
+    YMI_CHECK_ARG(dst->n == src->n && src->h == 2 * dst->h && src->w == 2 * dst->w && dst->c == src->c, "upsample2x_bwd_acc: shapes");
+    return launch_move<4>(src, dst, "upsample2x_bwd_acc", (hipStream_t)stream);
 }
 extern "C" int ymi_add_inplace(const ymi_tensor* src, const ymi_tensor* dst, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(src) && ymi_tensor_ok(dst) && ymi_same_shape(src, dst), "add_inplace: shapes");

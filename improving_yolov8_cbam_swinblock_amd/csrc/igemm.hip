@@ -38,11 +38,12 @@ struct IgemmArgs {
     const void* w;
     void* y;
     const void* res;
+    const void* res2;  // second addend of the epilogue (gradient sums of tensors with several consumers)
     const float* scale;
     const float* bias;
     float* partials;
     const void* zero;
-    int64_t ldx, ldy, ldres, ktot;
+    int64_t ldx, ldy, ldres, ldres2, ktot;
     int M, H, W, Ho, Wo, Hy, Wy;
     int s_in, s_out, oh_off, ow_off;
     int Cout, cpt, ntaps, KC;
@@ -297,21 +298,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
     // workgroup stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines
     // (per-lane 8-byte stores to 16 different rows cost 2-3x the time of the same bytes stored this way).
     const int l15 = lane & 15, l4 = lane >> 4;
-    T* __restrict__ yg = reinterpret_cast<T*>(a.y);
+    T* yg = reinterpret_cast<T*>(a.y);
     constexpr int ES = (int)sizeof(T);
     constexpr int CROW = BN * ES + 16;  // padded LDS row of the output image
     char* Cimg = smem;
     float* red = reinterpret_cast<float*>(smem + BM * CROW);  // [WM][2][BN] (STATS)
-    const T* __restrict__ rg = reinterpret_cast<const T*>(a.res);
+    const T* rg = reinterpret_cast<const T*>(a.res);    // (no __restrict__: an addend may be the output buffer itself, read before it is written)
+    const T* rg2 = reinterpret_cast<const T*>(a.res2);
 
-    auto out_offset = [&](int m) -> int64_t {
-        if (a.s_out == 1 && a.Hy == a.Ho && a.Wy == a.Wo) return (int64_t)m * a.ldy;
+    // output pixel (row of y, and of the epilogue addends) that GEMM row m produces
+    auto out_pixel = [&](int m) -> int64_t {
+        if (a.s_out == 1 && a.Hy == a.Ho && a.Wy == a.Wo) return (int64_t)m;
         const int t = fast_div(m, a.wo_mul, a.wo_shr, a.Wo);
         const int wo = m - t * a.Wo;
         const int n = fast_div(t, a.ho_mul, a.ho_shr, a.Ho);
         const int ho = t - n * a.Ho;
-        return (((int64_t)n * a.Hy + ho * a.s_out + a.oh_off) * a.Wy + wo * a.s_out + a.ow_off) * a.ldy;
+        return ((int64_t)n * a.Hy + ho * a.s_out + a.oh_off) * a.Wy + wo * a.s_out + a.ow_off;
     };
+    auto out_offset = [&](int m) -> int64_t { return out_pixel(m) * a.ldy; };
 
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -343,15 +347,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(acc[tn][tm][r] * sc[r] + bi[r], a.act);
                 if (rg && m < a.M) {
+                    const int64_t px = out_pixel(m);
                     if (a.vec_store && ch + 3 < a.Cout) {
                         float rr[4];
-                        Pack<T, 4>::load(rg + (int64_t)m * a.ldres + ch, rr);
+                        Pack<T, 4>::load(rg + px * a.ldres + ch, rr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                        if (rg2) {
+                            Pack<T, 4>::load(rg2 + px * a.ldres2 + ch, rr);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                        }
                     } else {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            if (ch + r < a.Cout) v[r] += to_f32(rg[(int64_t)m * a.ldres + ch + r]);
+                            if (ch + r < a.Cout) v[r] += to_f32(rg[px * a.ldres + ch + r]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch + r]) : 0.f);
                     }
                 }
             }
@@ -621,7 +631,16 @@ extern "C" int64_t ymi_conv_dgrad_pack_elems(int64_t o, int64_t i, int64_t kh, i
 
 extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw,
                                    int64_t stride, const ymi_tensor* dx, void* stream) {
+    return ymi_conv2d_bwd_data_add(dy, w_dgrad_packed, cin, kh, kw, stride, nullptr, nullptr, dx, stream);
+}
+
+extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw,
+                                       int64_t stride, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && w_dgrad_packed, "conv2d_bwd_data: bad tensor");
+    if (add1 || add2) {
+        YMI_CHECK_ARG(add1 && ymi_tensor_ok(add1) && ymi_same_shape(add1, dx) && add1->dtype == dx->dtype, "conv2d_bwd_data_add: first addend");
+        YMI_CHECK_ARG(!add2 || (ymi_tensor_ok(add2) && ymi_same_shape(add2, dx) && add2->dtype == dx->dtype), "conv2d_bwd_data_add: second addend");
+    }
     YMI_CHECK_ARG(dy->dtype == dx->dtype, "conv2d_bwd_data: dtype mismatch");
     const int ch = dy->dtype == YMI_BF16 ? 8 : 4;
     YMI_CHECK_ARG(dy->c % ch == 0 && dy->ld % ch == 0, "conv2d_bwd_data: dy channels must be a multiple of %d", ch);
@@ -650,12 +669,16 @@ extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_pac
             IgemmArgs a{};
             a.x = dy->data; a.w = wbase + woff * es; a.y = dx->data; a.zero = ymi_zero_page();
             a.ldx = dy->ld; a.ldy = dx->ld;
+            a.res = add1 ? add1->data : nullptr; a.ldres = add1 ? add1->ld : 0;
+            a.res2 = add2 ? add2->data : nullptr; a.ldres2 = add2 ? add2->ld : 0;
             a.M = (int)(dx->n * ho * wo); a.H = (int)dy->h; a.W = (int)dy->w; a.Ho = (int)ho; a.Wo = (int)wo; a.Hy = (int)dx->h; a.Wy = (int)dx->w;
             a.s_in = 1; a.s_out = (int)stride; a.oh_off = ph; a.ow_off = pw;
             a.Cout = (int)cin; a.cpt = (int)(dy->c / ch); a.ntaps = nt; a.KC = nt * a.cpt; a.ktot = (int64_t)a.KC * ch;
             pack_taps(dh, dw, nt, &a.tap_dh, &a.tap_dw);
             a.act = YMI_ACT_NONE;
-            a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0);
+            a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0) &&
+                          (!add1 || (add1->ld % 4 == 0 && ((uintptr_t)add1->data) % (4 * es) == 0)) &&
+                          (!add2 || (add2->ld % 4 == 0 && ((uintptr_t)add2->data) % (4 * es) == 0));
             finish_args(a, dx, nullptr);
             classes[nlaunch++] = a;
         } else if (ho > 0 && wo > 0) {

@@ -193,9 +193,10 @@ extern "C" int ymi_layernorm_fwd(const ymi_tensor* x, int64_t ws, const float* g
 // backward: dx = rstd*(g*dy - mean(g*dy) - xhat*mean(g*dy*xhat)); per-block partials of dgamma/dbeta.
 // ACCUM: dx += (used when the LayerNorm input also feeds a residual branch).
 template <typename T, int G>
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C,
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, SV add, int64_t Tn, int H, int W, int Hp, int Wp, int ws, int C,
                                                             const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, float* __restrict__ part, int accumulate) {
+                                                            const float* __restrict__ rstd, float* __restrict__ part) {
+    const bool accumulate = add.p != nullptr;  // dx = LN gradient + add (the other consumers' gradient of the LN input; may be dx itself)
     extern __shared__ float red_dyn[];  // [4 waves][2][Cr], Cr = C rounded up to 256: sized by the launcher, so 8+ workgroups fit a CU
     const int Cr = (C + 255) / 256 * 256;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, 
         float xh[G][4], d[G][4], prev[G][4];
         float s1 = 0.f, s2 = 0.f;
         T* op = reinterpret_cast<T*>(const_cast<void*>(dx.p)) + row * dx.ld;
+        const T* ap = reinterpret_cast<const T*>(add.p) + row * add.ld;
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int c = lane * 4 + 256 * i;
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, 
                 Pack<T, 4>::load(dp + c, d[i]);
                 // the value this pass accumulates onto: fetched WITH the operands, not after the reductions (it was a
                 // second dependent memory round trip per token)
-                if (accumulate && real) Pack<T, 4>::load(op + c, prev[i]);
+                if (accumulate && real) Pack<T, 4>::load(ap + c, prev[i]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     xh[i][r] = (v[r] - mu) * rs;
@@ -274,7 +276,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(SV x, SV dy, SV dx, 
     }
 }
 
-#define YMI_LNB(T, G) hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(blocks), dim3(256), red_bytes, s, xv, dv, ov, T_, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace, (int)accumulate)
+#define YMI_LNB(T, G) hipLaunchKernelGGL((layernorm_bwd_kernel<T, G>), dim3(blocks), dim3(256), red_bytes, s, xv, dv, ov, av, T_, (int)x->h, (int)x->w, (int)Hp, (int)Wp, (int)ws, (int)x->c, gamma, mean, rstd, (float*)workspace)
 
 static int ln_bwd_blocks(int64_t T) {
     int64_t b = (T + 31) / 32;  // >= 8 tokens per wave
@@ -286,6 +288,13 @@ static int ln_bwd_blocks(int64_t T) {
 extern "C" int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tensor* dout, const float* gamma, const float* mean,
                                  const float* rstd, const ymi_tensor* dx, int32_t accumulate, float* dgamma, float* dbeta, void* workspace,
                                  size_t workspace_bytes, void* stream) {
+    return ymi_layernorm_bwd_add(x, ws, dout, gamma, mean, rstd, accumulate ? dx : nullptr, dx, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+
+extern "C" int ymi_layernorm_bwd_add(const ymi_tensor* x, int64_t ws, const ymi_tensor* dout, const float* gamma, const float* mean,
+                                     const float* rstd, const ymi_tensor* add, const ymi_tensor* dx, float* dgamma, float* dbeta, void* workspace,
+                                     size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(!add || (ymi_tensor_ok(add) && ymi_same_shape(add, dx) && add->dtype == dx->dtype && add->ld % 4 == 0), "layernorm_bwd_add: addend");
     YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(dout) && ymi_tensor_ok(dx) && gamma && mean && rstd && dgamma && dbeta && workspace, "layernorm_bwd: args");
     YMI_CHECK_ARG(x->dtype == dout->dtype && x->dtype == dx->dtype && ymi_same_shape(x, dx), "layernorm_bwd: dtypes/shapes");
     YMI_CHECK_ARG(x->c == dout->c && x->c % 4 == 0 && x->c <= 1024 && x->ld % 4 == 0 && dout->ld % 4 == 0 && dx->ld % 4 == 0, "layernorm_bwd: channels");
@@ -300,7 +309,7 @@ extern "C" int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tens
         ymi_set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, need);
         return YMI_EWORKSPACE;
     }
-    SV xv{x->data, x->ld}, dv{dout->data, dout->ld}, ov{dx->data, dx->ld};
+    SV xv{x->data, x->ld}, dv{dout->data, dout->ld}, ov{dx->data, dx->ld}, av{add ? add->data : nullptr, add ? add->ld : 0};
     hipStream_t s = (hipStream_t)stream;
     const size_t red_bytes = (size_t)8 * ((x->c + 255) / 256 * 256) * sizeof(float);
     if (x->dtype == YMI_BF16)

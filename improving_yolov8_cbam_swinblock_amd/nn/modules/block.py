@@ -35,6 +35,8 @@ class Bottleneck(nn.Module):
 
     def forward(self, x, out=None):
         x = ops.to_internal(x)
+        if self.add and self.training and ops.join_of(x) is None:
+            ops.mark_join(x, 2)  # consumers of x here: cv1 and the shortcut; their gradient sum forms in cv1's data-gradient epilogue
         return self.cv2(self.cv1(x), residual=x if self.add else None, out=out)
 
 
@@ -49,7 +51,8 @@ class C2f(nn.Module):
         self.cv2 = Conv((2 + n) * self.c, c2, 1)
         self.m = nn.ModuleList(Bottleneck(self.c, self.c, shortcut, g, k=((3, 3), (3, 3)), e=1.0) for _ in range(n))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
+        """out: optional ops.OutSlot for the block's result (a slice of a later Concat's buffer; train mode)."""
         x = ops.to_internal(x)
         buf, slot = None, (lambda j: None)
         dt = x.dtype
@@ -60,10 +63,15 @@ class C2f(nn.Module):
             slot = lambda j: ops.OutSlot(buf, j * self.c)  # noqa: E731
         t, last = ops.c2f_split(self.cv1(x, out=slot(0)), self.c)  # (both chunks, second chunk): channel slices, no copy
         ys = [t]  # both chunks go into the concat at once: they are adjacent in memory
+        nm = len(self.m)
         for j, m in enumerate(self.m):
+            # consumers of a Bottleneck's input: its cv1, its shortcut (if any) and - for j >= 1, where the input is the
+            # previous Bottleneck's output - the concat; the right half of t reaches the concat through c2f_split instead
+            if buf is not None:
+                ops.mark_join(last, 1 + int(m.add) + int(j >= 1))
             last = m(last, out=slot(2 + j))
             ys.append(last)
-        return self.cv2(ops.concat(ys, buf))
+        return self.cv2(ops.concat(ys, buf), out=out)
 
     forward_split = forward
 
@@ -79,6 +87,6 @@ class SPPF(nn.Module):
         self.cv2 = Conv(c_ * 4, c2, 1, 1)
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)  # attribute kept for parity with the reference
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         y0 = self.cv1(x)
-        return self.cv2(ops.sppf_pool_cat(y0, self.m.kernel_size))
+        return self.cv2(ops.sppf_pool_cat(y0, self.m.kernel_size), out=out)

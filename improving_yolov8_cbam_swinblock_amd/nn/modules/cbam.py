@@ -42,10 +42,10 @@ class CBAM(nn.Module):
         self.ca = ChannelAttention(channels, ratio=8 if channels and channels < 128 else 16)
         self.sa = SpatialAttention(kernel_size=7)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = ops.to_internal(x)
         if self.ca.shared_MLP is None:
             self.ca.create_mlp(x.shape[1])
             self.ca.shared_MLP.to(x.device)
         mlp = self.ca.shared_MLP
-        return ops.cbam(x, mlp[0].weight, mlp[2].weight, self.sa.conv.weight)
+        return ops.cbam(x, mlp[0].weight, mlp[2].weight, self.sa.conv.weight, out)

@@ -80,9 +80,10 @@ class Concat(nn.Module):
             raise NotImplementedError("Concat along channels only")
         self.d = dimension
 
-    def forward(self, x):
+    def forward(self, x, buf=None):
+        """buf: the pre-allocated buffer whose slices the producers already wrote (model graph, train mode): no copies."""
         dt = ops.compute_dtype(x[0])
-        return ops.concat([ops.to_internal(t, dt) for t in x])
+        return ops.concat([ops.to_internal(t, dt) for t in x], buf)
 
 
 class Upsample(nn.Module):
@@ -95,5 +96,5 @@ class Upsample(nn.Module):
             raise NotImplementedError("only nearest 2x upsampling is on the hot path")
         self.size, self.scale_factor, self.mode = size, scale_factor, mode
 
-    def forward(self, x):
-        return ops.upsample2x(ops.to_internal(x))
+    def forward(self, x, out=None):
+        return ops.upsample2x(ops.to_internal(x), out)

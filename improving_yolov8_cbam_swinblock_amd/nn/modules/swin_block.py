@@ -36,18 +36,23 @@ class SwinBlock(nn.Module):
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = nn.Sequential(nn.Linear(dim, dim * 4), nn.GELU(), nn.Linear(dim * 4, dim))
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         x = ops.to_internal(x)
         n, c, h, w = x.shape
         ws = self.window_size
         if c != self.dim:
             raise RuntimeError(f"Given normalized_shape=[{self.dim}], expected input with {self.dim} channels, got {c}")
         a = self.attn
+        join = self.training  # t1 / t2 each feed a GEMM (or LayerNorm) and a residual: gradient sums form in those kernels
         t1 = ops.layernorm(x, self.norm1, ws)                                   # [T, C] window order, pad tokens = norm1.bias
+        if join:
+            ops.mark_join(t1, 2)
         qkv = ops.linear(t1, a.in_proj_weight, a.in_proj_bias)                  # [T, 3C]
         o = ops.window_attention(qkv, ws * ws, a.num_heads)                     # [T, C]
         t2 = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=t1)     # skip from normalised tokens
+        if join:
+            ops.mark_join(t2, 2)
         u = ops.layernorm(t2, self.norm2, 0)
         hdn = ops.gelu(ops.linear(u, self.mlp[0].weight, self.mlp[0].bias))
         t3 = ops.linear(hdn, self.mlp[2].weight, self.mlp[2].bias, residual=t2)
-        return ops.window_reverse(t3, n, h, w, ws)
+        return ops.window_reverse(t3, n, h, w, ws, out)

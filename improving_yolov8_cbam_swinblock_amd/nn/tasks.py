@@ -133,18 +133,70 @@ class BaseModel(nn.Module):
 
     def _predict_once(self, x, profile=False, visualize=False, embed=None, split_head=False):
         """the 27-step module loop of reference tasks.py:152-179.  split_head: return Detect's maps before
-        its channel concat (training loss fast path)."""
+        its channel concat (training loss fast path).
+        Training forwards use two facts of the layer graph (`_graph_plan`): the producers of a Concat layer write
+        straight into their slice of its buffer (no copies for conv.py:683 `torch.cat`), and a layer output with several
+        consumers carries an ops.GradJoin, so its gradient sum forms in a consumer's kernel instead of autograd adds."""
         y = []
         self._begin_weight_arena(x)
+        plan = self._graph_plan() if (self.training and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda) else None
+        bufs = {}
         with ops.deferred_bn_counters():
             for m in self.model:
                 if m.f != -1:
                     x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
                 if split_head and isinstance(m, Detect):
                     return SplitPreds(*m.forward_split(x))
-                x = m(x)
+                if plan is None:
+                    x = m(x)
+                elif isinstance(m, Concat):
+                    lazy = bufs.get(m.i)
+                    x = m(x, buf=lazy.buf if lazy is not None else None)
+                elif m.i in plan["slot"]:
+                    cidx, off, total = plan["slot"][m.i]
+                    lazy = bufs.get(cidx)
+                    if lazy is None:
+                        lazy = bufs[cidx] = ops.LazyConcatBuffer(total, x.device if torch.is_tensor(x) else x[0].device)
+                    x = m(x, out=ops.OutSlot(None, off, lazy))
+                else:
+                    x = m(x)
+                if plan is not None and split_head and torch.is_tensor(x):
+                    # only on the loss path, where every Detect input is known to receive a gradient: a join waits for ALL
+                    # its consumers, and a caller of model(img) may back-propagate through some of the outputs only
+                    ops.mark_join(x, plan["consumers"].get(m.i, 1))
                 y.append(x if m.i in self.save else None)
         return x
+
+    def _graph_plan(self):
+        """static facts of the layer graph, computed once: {"slot": {producer layer: (concat layer, channel offset, concat
+        channels)}, "consumers": {layer: number of join-aware consumers of its output (only where all consumers are)}}."""
+        plan = getattr(self, "_plan", None)
+        if plan is not None:
+            return plan
+        n = len(self.model)
+        srcs = []
+        for m in self.model:
+            f = [m.f] if isinstance(m.f, int) else list(m.f)
+            srcs.append([m.i - 1 if j == -1 else j for j in f])
+        outs = self._channel_trace(self.yaml.get("ch", 3))
+        slot_ok = (Conv, C2f, SPPF, CBAM, SwinBlock, Upsample)
+        join_ok = (Conv, C2f, SPPF, SwinBlock, Upsample, Concat, Detect)
+        slot, consumers, ok = {}, {}, {}
+        for m in self.model:
+            for j in srcs[m.i]:
+                if j < 0:
+                    continue
+                consumers[j] = consumers.get(j, 0) + (2 if isinstance(m, Detect) else 1)  # Detect reads each input with two branches
+                ok[j] = ok.get(j, True) and isinstance(m, join_ok)
+            if isinstance(m, Concat):
+                off, total = 0, sum(outs[j][0] for j in srcs[m.i])
+                for j in srcs[m.i]:
+                    c = outs[j][0]
+                    if j >= 0 and j not in slot and isinstance(self.model[j], slot_ok) and off % 8 == 0 and c % 8 == 0:
+                        slot[j] = (m.i, off, total)
+                    off += c
+        plan = self._plan = {"slot": slot, "consumers": {j: c for j, c in consumers.items() if c > 1 and ok[j]}}
+        return plan
 
     def _begin_weight_arena(self, x):
         """training forwards pack every weight with one launch (ops.WeightArena): the first forward+backward records

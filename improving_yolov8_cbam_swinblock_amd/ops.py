@@ -310,8 +310,82 @@ def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias):
     return out
 
 
-def _dgrad(dy, weight4, k, stride, in_shape, dtype):
-    """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight; zero-padded input channels get zero."""
+class GradJoin:
+    """Gradient sum of a tensor with several consumers, formed inside kernels instead of by autograd `add`s.
+
+    The module that creates the tensor (and knows every consumer is one of this package's ops) hands the same GradJoin to
+    all `n` consumers.  In backward every consumer but the last to run DEPOSITS its gradient contribution here and returns
+    None to autograd; the last one fetches the deposits and adds them in the epilogue of its own kernel (data-gradient
+    GEMM, LayerNorm backward, upsample adjoint) - or, if it has no such kernel, with explicit accumulate launches.
+    Which consumer is last is decided at run time, so the result does not depend on autograd's node order.
+    Reference sites: Bottleneck shortcut (block.py:488), the two Detect branches (head.py:72), neck skip connections
+    (yolov8.yaml:760-773), SwinBlock residuals (swin_block.py:52-53), C2f chunk / concat (block.py:302-304)."""
+
+    __slots__ = ("n", "seen", "pending")
+
+    def __init__(self, n):
+        self.n, self.seen, self.pending = int(n), 0, []
+
+    def arrive(self):
+        """-> the deposits if the caller is the last consumer (it must return the total), else None (it must deposit)."""
+        self.seen += 1
+        if self.seen < self.n:
+            return None
+        out, self.pending, self.seen = self.pending, [], 0
+        return out
+
+    def deposit(self, g):
+        self.pending.append(g)
+
+
+def mark_join(t, consumers):
+    """attach a GradJoin for `consumers` join-aware consumers to tensor t (training, grad enabled, > 1 consumer)."""
+    if consumers > 1 and torch.is_grad_enabled() and t.requires_grad:
+        t._ymi_join = GradJoin(consumers)
+    return t
+
+
+def join_of(t):
+    return getattr(t, "_ymi_join", None) if torch.is_grad_enabled() else None
+
+
+def _accumulate(total, adds):
+    """total += each addend (explicit launches: the fall-back of consumers without a fusing kernel); total is private."""
+    for a in adds:
+        a = grad_nhwc(a, total.dtype) if a.dim() == 4 else a.to(total.dtype)
+        check(L().ymi_add_inplace(_byref(as_ymi(a)), _byref(as_ymi(total)), stream_ptr()), "add_inplace")
+    return total
+
+
+def _join_plain(join, g):
+    """consumer without a fusing kernel (residual hand-through, concat slice): deposit, or return the total if last."""
+    if join is None:
+        return g
+    adds = join.arrive()
+    if adds is None:
+        join.deposit(g)
+        return None
+    if not adds:
+        return g
+    total = empty_nhwc(*g.shape, g.dtype, g.device) if g.dim() == 4 else torch.empty_like(g)
+    total.copy_(g)
+    return _accumulate(total, adds)
+
+
+def _prep_adds(adds, dtype, like4d):
+    """addends as tensors the epilogue can read: same dtype, NHWC memory (4-D) / unit channel stride (2-D)."""
+    out = []
+    for a in adds or ():
+        if a.dtype != dtype:
+            a = a.to(dtype)
+        a = grad_nhwc(a, dtype)
+        out.append(a)
+    return out
+
+
+def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None):
+    """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight (+ up to two addends summed in the GEMM's
+    epilogue, further ones by accumulate launches); zero-padded input channels get zero."""
     n, cp, h, w = in_shape
     cin = weight4.shape[1]
     ty = as_ymi(dy)
@@ -321,7 +395,25 @@ def _dgrad(dy, weight4, k, stride, in_shape, dtype):
     if cp != cin:
         dx.zero_()
         dxv = dx[:, :cin]
-    check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), cin, k, k, stride, _byref(as_ymi(dxv)), stream_ptr()), "conv2d_bwd_data")
+    adds = _prep_adds(adds, dtype, True)
+    fused = adds[:2] if cp == cin else []
+    a1 = _byref(as_ymi(fused[0])) if len(fused) > 0 else None
+    a2 = _byref(as_ymi(fused[1])) if len(fused) > 1 else None
+    check(L().ymi_conv2d_bwd_data_add(_byref(ty), ptr(wd), cin, k, k, stride, a1, a2, _byref(as_ymi(dxv)), stream_ptr()), "conv2d_bwd_data")
+    if len(adds) > len(fused):
+        _accumulate(dxv, adds[len(fused):])
+    return dx
+
+
+def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype):
+    """data gradient of a consumer of a joined tensor: deposits (and returns None) unless it is the last consumer."""
+    if join is None:
+        return _dgrad(dy, weight4, k, stride, in_shape, dtype)
+    adds = join.arrive()
+    dx = _dgrad(dy, weight4, k, stride, in_shape, dtype, adds)
+    if adds is None:
+        join.deposit(dx)
+        return None
     return dx
 
 
@@ -331,14 +423,29 @@ class OutSlot:
     concat itself (block.py:304 `torch.cat`) needs no copy.  A plain Python object: the buffer is storage only and
     never takes part in autograd; the producer's output is a view created inside its Function.forward."""
 
-    def __init__(self, buf, off):
-        self.buf, self.off = buf, int(off)
+    def __init__(self, buf, off, lazy=None):
+        self.buf, self.off, self.lazy = buf, int(off), lazy
 
     def view(self, n, c, h, w, dtype):
+        if self.buf is None and self.lazy is not None:  # concat buffer of the model graph: created by its first producer
+            self.buf = self.lazy.get(n, h, w, dtype)
         b = self.buf
         if b.dtype != dtype or b.shape[0] != n or b.shape[2] != h or b.shape[3] != w or self.off + c > b.shape[1]:
             raise RuntimeError(f"output slot [{self.off}:{self.off + c}] of {tuple(b.shape)} {b.dtype} does not fit a {(n, c, h, w)} {dtype} result")
         return b[:, self.off : self.off + c]
+
+
+class LazyConcatBuffer:
+    """the NHWC buffer of one Concat layer of the model graph: every producer writes its slice (OutSlot), the Concat
+    itself copies nothing (nn/modules/conv.py:683 `torch.cat` of the reference).  Allocated when the first producer runs."""
+
+    def __init__(self, channels, device):
+        self.channels, self.device, self.buf = int(channels), device, None
+
+    def get(self, n, h, w, dtype):
+        if self.buf is None:
+            self.buf = empty_nhwc(n, self.channels, h, w, dtype, self.device)
+        return self.buf
 
 
 class _ConvBnAct(torch.autograd.Function):
@@ -346,7 +453,7 @@ class _ConvBnAct(torch.autograd.Function):
     (+ Bottleneck add, nn/modules/block.py:488)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum, act, residual, slot=None):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum, act, residual, slot=None, join=None, res_join=None):
         dtype = x.dtype
         o, i, k, _ = weight.shape
         n, cp, h, w = x.shape
@@ -370,6 +477,7 @@ class _ConvBnAct(torch.autograd.Function):
         )
         ctx.save_for_backward(x, weight, gamma, beta, raw, stats)
         ctx.cfg = (stride, act, i, residual is not None)
+        ctx.joins = (join, res_join)
         return out
 
     @staticmethod
@@ -390,19 +498,24 @@ class _ConvBnAct(torch.autograd.Function):
                                _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
             "bn_act_bwd",
         )
+        join, res_join = ctx.joins
+        # the residual hand-through first: when x is both the input and the residual (Bottleneck shortcut), the data
+        # gradient below is then the join's last consumer and adds `dout` in its epilogue
+        dres = _join_plain(res_join, dout) if (has_res and ctx.needs_input_grad[10]) else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _dgrad(draw, weight, k, stride, x.shape, dtype)
+            dx = _dgrad_joined(join, draw, weight, k, stride, x.shape, dtype)
         dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False)
-        dres = dout if (has_res and ctx.needs_input_grad[10]) else None
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
 
 
 def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
-    """train-mode Conv block on an internal (NHWC) tensor; updates bn.running_* in place.  slot: optional OutSlot."""
+    """train-mode Conv block on an internal (NHWC) tensor; updates bn.running_* in place.  slot: optional OutSlot.
+    Tensors marked with mark_join() (several consumers) have their gradient sums formed in the data-gradient epilogue."""
     if bn.momentum is None:
         raise RuntimeError("BatchNorm with cumulative moving average (momentum=None) is not supported")
-    out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual, slot)
+    out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual, slot,
+                           join_of(x), join_of(residual) if residual is not None else None)
     if bn.num_batches_tracked is not None:
         if _deferred_counters is not None:
             _deferred_counters.append(bn.num_batches_tracked)
@@ -439,7 +552,7 @@ class _ConvAffineAct(torch.autograd.Function):
     (head.py:45-59) and every nn.Linear of SwinBlock (swin_block.py:29-35) with k = 1."""
 
     @staticmethod
-    def forward(ctx, x, weight, scale, bias, stride, act, residual, cout_pad):
+    def forward(ctx, x, weight, scale, bias, stride, act, residual, cout_pad, join=None, res_join=None):
         dtype = x.dtype
         w4 = _as4d(weight)
         o, i, k, _ = w4.shape
@@ -468,6 +581,7 @@ class _ConvAffineAct(torch.autograd.Function):
             ctx.unsupported = None
         ctx.save_for_backward(x, weight)
         ctx.cfg = (stride, i, bias is not None, residual is not None, cout_pad)
+        ctx.joins = (join, res_join)
         return y
 
     @staticmethod
@@ -480,28 +594,38 @@ class _ConvAffineAct(torch.autograd.Function):
         w4 = _as4d(weight)
         o, _, k, _ = w4.shape
         dy = grad_nhwc(dy, dtype)
+        join, res_join = ctx.joins
+        dres = None
+        if has_res and ctx.needs_input_grad[6]:
+            dres = _join_plain(res_join, dy[:, :o] if cout_pad != o else dy)
         dx = None
         if ctx.needs_input_grad[0]:
             if x.dim() == 4:
-                dx = _dgrad(dy, w4, k, stride, x.shape, dtype)
+                dx = _dgrad_joined(join, dy, w4, k, stride, x.shape, dtype)
             else:
+                adds = join.arrive() if join is not None else []
                 ty = as_ymi(dy)
                 wd = pack_conv_dgrad(weight, ty.c, 1, dtype)
                 dx = torch.empty((x.shape[0], x.shape[1]), dtype=dtype, device=x.device)
-                check(L().ymi_conv2d_bwd_data(_byref(ty), ptr(wd), x.shape[1], 1, 1, 1, _byref(as_ymi(dx)), stream_ptr()), "conv2d_bwd_data")
+                fa = _prep_adds(adds, dtype, False)
+                a1 = _byref(as_ymi(fa[0])) if len(fa) > 0 else None
+                a2 = _byref(as_ymi(fa[1])) if len(fa) > 1 else None
+                check(L().ymi_conv2d_bwd_data_add(_byref(ty), ptr(wd), x.shape[1], 1, 1, 1, a1, a2, _byref(as_ymi(dx)), stream_ptr()), "conv2d_bwd_data")
+                if len(fa) > 2:
+                    _accumulate(dx, fa[2:])
+                if adds is None:
+                    join.deposit(dx)
+                    dx = None
         dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias)
         dw = dw.view(weight.shape)
-        dres = None
-        if has_res and ctx.needs_input_grad[6]:
-            dres = dy[:, :o] if cout_pad != o else dy
-        return dx, dw, None, db, None, None, dres, None
+        return dx, dw, None, db, None, None, dres, None, None, None
 
 
 def conv_affine_act(x, weight, scale=None, bias=None, stride=1, act=ACT_NONE, residual=None, pad_out=False):
     w4 = _as4d(weight)
     o = w4.shape[0]
     cout_pad = round_up(o, chunk_elems(x.dtype)) if pad_out else o
-    y = _ConvAffineAct.apply(x, weight, scale, bias, int(stride), int(act), residual, cout_pad)
+    y = _ConvAffineAct.apply(x, weight, scale, bias, int(stride), int(act), residual, cout_pad, join_of(x), join_of(residual) if residual is not None else None)
     if cout_pad != o:
         y = y[:, :o]
     return y
@@ -509,7 +633,7 @@ def conv_affine_act(x, weight, scale=None, bias=None, stride=1, act=ACT_NONE, re
 
 def linear(x, weight, bias=None, residual=None):
     """token GEMM: x [T, Cin] @ weight[Cout, Cin]^T + bias (+ residual)."""
-    return _ConvAffineAct.apply(x, weight, None, bias, 1, ACT_NONE, residual, weight.shape[0])
+    return _ConvAffineAct.apply(x, weight, None, bias, 1, ACT_NONE, residual, weight.shape[0], join_of(x), join_of(residual) if residual is not None else None)
 
 
 class _Act(torch.autograd.Function):
@@ -543,7 +667,7 @@ class _Concat(torch.autograd.Function):
     """channel concat by strided copies into one NHWC buffer (conv.py:683, block.py:226,304)."""
 
     @staticmethod
-    def forward(ctx, buf, *xs):
+    def forward(ctx, buf, joins, *xs):
         n, _, h, w = xs[0].shape
         cs = [t.shape[1] for t in xs]
         out = buf if buf is not None else empty_nhwc(n, sum(cs), h, w, xs[0].dtype, xs[0].device)
@@ -556,20 +680,21 @@ class _Concat(torch.autograd.Function):
                 check(L().ymi_copy(_byref(as_ymi(t)), _byref(as_ymi(dst)), stream_ptr()), "copy")
             off += c
         ctx.cs = cs
+        ctx.joins = joins
         return out if buf is None else out[:, :]
 
     @staticmethod
     def backward(ctx, g):
         outs, off = [], 0
-        for c in ctx.cs:
-            outs.append(g[:, off : off + c])
+        for c, j in zip(ctx.cs, ctx.joins):
+            outs.append(_join_plain(j, g[:, off : off + c]))  # inputs with other consumers: the slice is deposited for the last of them
             off += c
-        return (None, *outs)
+        return (None, None, *outs)
 
 
 def concat(xs, buf=None):
     """channel concat; buf: optional pre-allocated NHWC buffer whose slices some inputs already alias (OutSlot)."""
-    return _Concat.apply(buf, *xs)
+    return _Concat.apply(buf, tuple(join_of(t) for t in xs), *xs)
 
 
 class _C2fSplit(torch.autograd.Function):
@@ -606,26 +731,40 @@ def c2f_split(t, c):
 
 
 class _Upsample2x(torch.autograd.Function):
-    """nn.Upsample(None, 2, 'nearest') (yolov8.yaml:759,764) and its adjoint (2x2 block sums)."""
+    """nn.Upsample(None, 2, 'nearest') (yolov8.yaml:759,764) and its adjoint (2x2 block sums).  slot: write into a slice
+    of the consuming Concat's buffer; join: the input has other consumers, whose gradient the adjoint accumulates onto."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, slot=None, join=None):
         n, c, h, w = x.shape
-        out = empty_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
+        out = slot.view(n, c, 2 * h, 2 * w, x.dtype) if slot is not None else empty_nhwc(n, c, 2 * h, 2 * w, x.dtype, x.device)
         check(L().ymi_upsample2x(_byref(as_ymi(x)), _byref(as_ymi(out)), stream_ptr()), "upsample2x")
+        ctx.join = join
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = grad_nhwc(g, g.dtype)
         n, c, h, w = g.shape
+        adds = ctx.join.arrive() if ctx.join is not None else []
+        if adds:
+            # the other consumers' gradient (e.g. the slice a Concat's consumer wrote for this tensor) is private to this
+            # join: accumulate the block sums onto it in place
+            dx = grad_nhwc(adds[0], g.dtype)
+            check(L().ymi_upsample2x_bwd_acc(_byref(as_ymi(g)), _byref(as_ymi(dx)), stream_ptr()), "upsample2x_bwd_acc")
+            if len(adds) > 1:
+                _accumulate(dx, adds[1:])
+            return dx, None, None
         dx = empty_nhwc(n, c, h // 2, w // 2, g.dtype, g.device)
         check(L().ymi_upsample2x_bwd(_byref(as_ymi(g)), _byref(as_ymi(dx)), stream_ptr()), "upsample2x_bwd")
-        return dx
+        if adds is None:
+            ctx.join.deposit(dx)
+            return None, None, None
+        return dx, None, None
 
 
-def upsample2x(x):
-    return _Upsample2x.apply(x)
+def upsample2x(x, slot=None):
+    return _Upsample2x.apply(x, slot, join_of(x))
 
 
 # ----------------------------------------------------------------------------------- SPPF pools
@@ -669,12 +808,12 @@ class _Cbam(torch.autograd.Function):
     """cbam.py:62-71 (channel attention :29-38, spatial attention :48-53)."""
 
     @staticmethod
-    def forward(ctx, x, w1, w2, wsa):
+    def forward(ctx, x, w1, w2, wsa, slot=None):
         n, c, h, w = x.shape
         hidden = w1.shape[0]
         ksa = wsa.shape[-1]
         dev = x.device
-        out = empty_nhwc(n, c, h, w, x.dtype, dev)
+        out = slot.view(n, c, h, w, x.dtype) if slot is not None else empty_nhwc(n, c, h, w, x.dtype, dev)
         f32 = dict(dtype=torch.float32, device=dev)
         i32 = dict(dtype=torch.int32, device=dev)
         ca = torch.empty((n, c), **f32)
@@ -710,11 +849,11 @@ class _Cbam(torch.autograd.Function):
                              ptr(smap), ptr(smap_arg), ptr(sa), _byref(as_ymi(dx)), ptr(dw1), ptr(dw2), ptr(dwsa), ptr(ws), ws.numel(), stream_ptr()),
             "cbam_bwd",
         )
-        return dx, dw1.view(w1.shape), dw2.view(w2.shape), dwsa.view(wsa.shape)
+        return dx, dw1.view(w1.shape), dw2.view(w2.shape), dwsa.view(wsa.shape), None
 
 
-def cbam(x, w1, w2, wsa):
-    return _Cbam.apply(x, w1, w2, wsa)
+def cbam(x, w1, w2, wsa, slot=None):
+    return _Cbam.apply(x, w1, w2, wsa, slot)
 
 
 # ----------------------------------------------------------------------------------- SwinBlock
@@ -727,7 +866,7 @@ class _LayerNorm(torch.autograd.Function):
     (pad + rearrange + window_partition + norm1, swin_block.py:41-50); ws == 0: x is a token matrix (norm2)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, ws):
+    def forward(ctx, x, gamma, beta, eps, ws, join=None):
         dev = x.device
         if ws > 0:
             n, c, h, w = x.shape
@@ -740,6 +879,7 @@ class _LayerNorm(torch.autograd.Function):
         check(L().ymi_layernorm_fwd(_byref(as_ymi(x)), ws, ptr(gamma), ptr(beta), eps, _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), stream_ptr()), "layernorm_fwd")
         ctx.save_for_backward(x, gamma, stats)
         ctx.ws = ws
+        ctx.join = join
         return out
 
     @staticmethod
@@ -752,16 +892,25 @@ class _LayerNorm(torch.autograd.Function):
         dx = empty_nhwc(*x.shape, x.dtype, dev) if ws > 0 else torch.empty_like(x)
         dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
         wsb = workspace(2048 * 2 * c * 4 + 256, dev, "ln")
+        adds = ctx.join.arrive() if ctx.join is not None else []
+        fa = _prep_adds(adds, x.dtype, ws > 0)
+        if ws > 0 and fa and fa[0].shape != x.shape:
+            raise RuntimeError("layernorm backward: addend shape")
         check(
-            L().ymi_layernorm_bwd(_byref(as_ymi(x)), ws, _byref(as_ymi(g)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), _byref(as_ymi(dx)), 0,
-                                  ptr(dgb[0]), ptr(dgb[1]), ptr(wsb), wsb.numel(), stream_ptr()),
+            L().ymi_layernorm_bwd_add(_byref(as_ymi(x)), ws, _byref(as_ymi(g)), ptr(gamma), ptr(stats[0]), ptr(stats[1]),
+                                      _byref(as_ymi(fa[0])) if fa else None, _byref(as_ymi(dx)), ptr(dgb[0]), ptr(dgb[1]), ptr(wsb), wsb.numel(), stream_ptr()),
             "layernorm_bwd",
         )
-        return dx, dgb[0], dgb[1], None, None
+        if len(fa) > 1:
+            _accumulate(dx, fa[1:])
+        if adds is None:
+            ctx.join.deposit(dx)
+            dx = None
+        return dx, dgb[0], dgb[1], None, None, None
 
 
 def layernorm(x, ln, ws=0):
-    return _LayerNorm.apply(x, ln.weight, ln.bias, float(ln.eps), int(ws))
+    return _LayerNorm.apply(x, ln.weight, ln.bias, float(ln.eps), int(ws), join_of(x))
 
 
 class _WindowAttention(torch.autograd.Function):
@@ -800,9 +949,9 @@ class _WindowReverse(torch.autograd.Function):
     """tokens -> NHWC image with the padding cropped (window_reverse + rearrange + crop, swin_block.py:55-58)."""
 
     @staticmethod
-    def forward(ctx, tokens, n, h, w, ws):
+    def forward(ctx, tokens, n, h, w, ws, slot=None):
         c = tokens.shape[1]
-        out = empty_nhwc(n, c, h, w, tokens.dtype, tokens.device)
+        out = slot.view(n, c, h, w, tokens.dtype) if slot is not None else empty_nhwc(n, c, h, w, tokens.dtype, tokens.device)
         check(L().ymi_window_reverse(_byref(as_ymi(tokens)), ws, _byref(as_ymi(out)), stream_ptr()), "window_reverse")
         ctx.cfg = (ws, tokens.shape[0])
         return out
@@ -813,11 +962,11 @@ class _WindowReverse(torch.autograd.Function):
         g = grad_nhwc(g, g.dtype)
         d = torch.empty((t, g.shape[1]), dtype=g.dtype, device=g.device)
         check(L().ymi_window_partition(_byref(as_ymi(g)), ws, _byref(as_ymi(d)), stream_ptr()), "window_partition")
-        return d, None, None, None, None
+        return d, None, None, None, None, None
 
 
-def window_reverse(tokens, n, h, w, ws):
-    return _WindowReverse.apply(tokens, int(n), int(h), int(w), int(ws))
+def window_reverse(tokens, n, h, w, ws, slot=None):
+    return _WindowReverse.apply(tokens, int(n), int(h), int(w), int(ws), slot)
 
 
 def window_partition_index(n, hp, wp, ws, device):

@@ -74,6 +74,8 @@ int ymi_copy(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
 int ymi_upsample2x(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
 /* adjoint: dst[n,h,w,:] = sum of the 2x2 block of src. */
 int ymi_upsample2x_bwd(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
+/* adjoint accumulated onto dst: dst[n,h,w,:] += sum of the 2x2 block of src (dst already holds the other consumers' gradient). */
+int ymi_upsample2x_bwd_acc(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
 /* dst += src (f32 accumulate, elementwise over NHWC tensors of equal shape). */
 int ymi_add_inplace(const ymi_tensor* src, const ymi_tensor* dst, void* stream);
 
@@ -146,6 +148,12 @@ int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, const float* g
 /* dx = conv_transpose(dy, w): operand packed by ymi_pack_conv_weight_dgrad.  Adjoint of conv.py:79. */
 int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
                         const ymi_tensor* dx, void* stream);
+/* the same with up to two addends in the epilogue: dx = dgrad(dy) + add1 (+ add2).  An addend may BE dx (in-place
+ * accumulation).  This is how the gradient sums of tensors with several consumers (Bottleneck shortcut block.py:488, the
+ * two Detect branches head.py:72, neck skip connections yolov8.yaml:760-773, SwinBlock residuals swin_block.py:52-53) are
+ * formed without separate add kernels. */
+int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
+                            const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream);
 /* dw (OIHW f32 [cout_real][cin_real][kh][kw], overwritten) = sum over pixels dy (x) x ; optional
  * dbias[cout_real] = column sums of dy.  x / dy may carry zero-padded channels (x->c >= cin_real,
  * dy->c >= cout_real).  Split-K MFMA GEMM + ordered slab reduce (deterministic); workspace from
@@ -200,6 +208,11 @@ int ymi_layernorm_fwd(const ymi_tensor* x, int64_t ws, const float* gamma, const
 int ymi_layernorm_bwd(const ymi_tensor* x, int64_t ws, const ymi_tensor* dout, const float* gamma, const float* mean,
                       const float* rstd, const ymi_tensor* dx, int32_t accumulate, float* dgamma, float* dbeta, void* workspace,
                       size_t workspace_bytes, void* stream);
+/* the same with an addend: dx = LayerNorm gradient + add (the gradient the LN input receives from its other consumers,
+ * e.g. the residual branch of swin_block.py:52-53); add may be dx itself. */
+int ymi_layernorm_bwd_add(const ymi_tensor* x, int64_t ws, const ymi_tensor* dout, const float* gamma, const float* mean, const float* rstd,
+                          const ymi_tensor* add, const ymi_tensor* dx, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes,
+                          void* stream);
 /* Window attention core of nn.MultiheadAttention as used at swin_block.py:29,51:
  * qkv [T][3C] (q pre-scaled is NOT assumed: the kernel scales by 1/sqrt(hd)); per (window, head)
  * P = softmax(q k^T / sqrt(hd)) over all `wlen` keys, o = P v; out [T][C].  lse [T][heads] saved. */

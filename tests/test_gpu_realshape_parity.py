@@ -80,9 +80,15 @@ def _oracle_run(oracle, batch):
 
 
 def _product_step(model, batch, dtype):
+    """the training path exactly as engine.trainer.TrainStep drives it: model(batch) -> (loss * B, items), backward
+    (so the graph-level concat slots and gradient joins of nn/tasks.py are what is tested); the Detect maps for the
+    forward comparison come from a second, gradient-free forward of the same weights."""
     with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
-        preds = model(batch["img"])
-        loss, _ = model.init_criterion()(preds, batch)
+        with torch.no_grad():
+            stats = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+            preds = model(batch["img"])
+            model.load_state_dict(stats, strict=False)  # the extra forward must not move the BatchNorm running statistics
+        loss, _ = model(batch)
     loss.sum().backward()
     torch.cuda.synchronize()
     return preds, loss.detach(), {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
