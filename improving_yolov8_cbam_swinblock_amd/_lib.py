@@ -74,6 +74,8 @@ _SIGNATURES = {
     "ymi_conv2d_bwd_data_add": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp]),
     "ymi_conv2d_bwd_weight": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_weight_workspace": (_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
+    "ymi_conv2d_bwd_weight_deferred": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ymi_wgrad_reduce_batch": (_c_i32, [_vp, _c_i32, _vp, _vp]),
     "ymi_sppf_pool3_fwd": (_c_i32, [_TP, _c_i64, _TP, _TP, _TP, _vp]),
     "ymi_sppf_pool3_bwd": (_c_i32, [_TP, _TP, _TP, _c_i64, _TP, _TP, _TP, _TP, _vp]),
     "ymi_cbam_fwd": (_c_i32, [_TP, _vp, _vp, _c_i64, _vp, _c_i64, _TP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
@@ -101,6 +103,11 @@ _SIGNATURES = {
 }
 
 OPT_MAX_GRADS = 448  # YMI_OPT_MAX_GRADS
+
+
+class WgradPending(ctypes.Structure):
+    _fields_ = [("slab", _vp), ("dw", _vp), ("elems", _c_i64), ("splits", _c_i32), ("ng", _c_i32), ("cin", _c_i32), ("cout_real", _c_i32),
+                ("cin_real", _c_i32), ("ntaps", _c_i32), ("lanes", _c_i32), ("first_block", _c_i32), ("blocks", _c_i32), ("_pad", _c_i32)]
 
 
 class OptEntry(ctypes.Structure):

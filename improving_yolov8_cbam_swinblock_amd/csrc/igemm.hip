@@ -118,8 +118,14 @@ template <> struct Mma<float> {
 };
 
 
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS>
-__global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
+// SPEC: wave specialisation.  512-thread workgroup: waves 0-3 multiply (LDS fragment reads + MFMA, the same 2x2 wave grid),
+// waves 4-7 only load (address generation + LDS-DMA into an NS-deep ring, counted vmcnt).  An LDS-DMA piece costs its
+// issuing wave 100-185 cycles inside a phase that also carries fragment reads and MFMAs (MI355X_MICROARCH.md, LDS-DMA
+// piece issue cost): 8 pieces per K step on the multiplying waves cost more than their 32 MFMAs (512 cycles) - the
+// reason ring depth never helped the unspecialised kernel.  Each SIMD now holds one multiplying and one loading wave
+// of the workgroup; the two roles meet at ONE barrier per K step.
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false>
+__global__ __launch_bounds__(SPEC ? 512 : 256) void igemm_kernel(IgemmMulti P) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int ROWB = CPR * 16;                    // bytes per LDS row = K step per row (64: 32 bf16 / 16 f32; 128: 64 bf16)
@@ -131,8 +137,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
     static_assert(BM % 64 == 0, "every wave issues all A loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
+    constexpr int NT = SPEC ? 512 : 256;
+    const int tid_all = threadIdx.x, lane = tid_all & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);  // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
+    const bool loader = !SPEC || wave_all >= 4, consumer = !SPEC || wave_all < 4;
+    const int tid = tid_all & 255, wave = wave_all & 3;  // index inside the role's four waves
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id & 7), each with its own L2.  Every XCD gets a
     // CONTIGUOUS range of M blocks (neighbouring pixel tiles share 3x3 halo rows) and walks the N blocks of one M block
@@ -275,21 +284,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
     constexpr int LPT_AONLY = NA;  // waves beyond the B tile's rows (BN < 64) issue no B loads
     const bool b_wave = (BN >= RPI) || (wave * RPW < BN);
     const int nkt = (a.KC + CPR - 1) / CPR;
+    if (loader) {
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s)
-        if (s < nkt) issue(s);
+        for (int s = 0; s < NS - 1; ++s)
+            if (s < nkt) issue(s);
+    }
     for (int kt = 0; kt < nkt; ++kt) {
-        // K step kt has landed when at most the loads of the NS-2 younger steps are outstanding
-        if (kt + NS - 2 < nkt) {
-            if (b_wave) wait_vmcnt_barrier<LPT_FULL * (NS - 2)>();
-            else wait_vmcnt_barrier<LPT_AONLY * (NS - 2)>();
+        if (loader) {
+            // K step kt has landed when at most the loads of the NS-2 younger steps are outstanding
+            if (kt + NS - 2 < nkt) {
+                if (b_wave) wait_vmcnt_barrier<LPT_FULL * (NS - 2)>();
+                else wait_vmcnt_barrier<LPT_AONLY * (NS - 2)>();
+            } else {
+                wait_vmcnt_barrier<0>();  // pipeline tail: fewer steps in flight than the count assumes
+            }
+            // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
+            if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
         } else {
-            wait_vmcnt_barrier<0>();  // pipeline tail: fewer steps in flight than the count assumes
+            asm volatile("s_barrier" ::: "memory");  // the loading waves waited for step kt's pieces before they arrived here
         }
-        // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
-        if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
-        const char* As = smem + (kt % NS) * STAGE;
-        Mma<T>::template step<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
+        if (consumer) {
+            const char* As = smem + (kt % NS) * STAGE;
+            Mma<T>::template step<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
 
@@ -317,6 +334,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
     };
     auto out_offset = [&](int m) -> int64_t { return out_pixel(m) * a.ldy; };
 
+    if (consumer) {
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int chl = (wn * TN + tn) * 16 + 4 * l4;  // channel within the block tile
@@ -396,10 +414,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
             }
         }
     }
+    }  // consumer
     __syncthreads();
     if constexpr (STATS) {
-        if (tid < 2 * BN) {
-            const int which = tid / BN, chl = tid % BN;
+        if (tid_all < 2 * BN) {
+            const int which = tid_all / BN, chl = tid_all % BN;
             float sum = 0.f;
 #pragma unroll
             for (int q = 0; q < WM; ++q) sum += red[(q * 2 + which) * BN + chl];
@@ -411,7 +430,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IgemmMulti P) {
         constexpr int CPW = BN * ES / 16;  // 16-byte chunks per output row
         constexpr int EPC = 16 / ES;       // elements per chunk
 #pragma unroll 4
-        for (int idx = tid; idx < BM * CPW; idx += 256) {
+        for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
             const int row = idx / CPW, cc = idx % CPW;
             const int m = m0 + row, ch = n0 + cc * EPC;
             if (m < a.M && ch < a.Cout) {
@@ -481,18 +500,24 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     dim3 grid((unsigned)(8 * mpx * a.nnb * ncls));
     const bool fast = (a.cpt % 4) == 0;
     static const int rowb_env = getenv("YMI_IGEMM_ROWB") ? atoi(getenv("YMI_IGEMM_ROWB")) : 0;
+    static const int spec_env = getenv("YMI_IGEMM_SPEC") ? atoi(getenv("YMI_IGEMM_SPEC")) : 0;  // 1: wave-specialised form (measured 12-20 % SLOWER, profiles/r02_conv_bench_spec.txt: kept as a knob)
     const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0 && rowb_env != 64;
-    size_t lds = (size_t)2 * (t.bm + t.bn) * (wide ? 128 : 64);
+    const bool spec = wide && spec_env != 0;  // wave-specialised form: the bf16 128-byte-row kernels (every layer but the first)
+    static const int spec_ns = getenv("YMI_IGEMM_SPEC_NS") ? atoi(getenv("YMI_IGEMM_SPEC_NS")) : 3;
+    size_t lds = (size_t)(spec ? spec_ns : 2) * (t.bm + t.bn) * (wide ? 128 : 64);
     const size_t epi = (size_t)t.bm * (t.bn * sizeof(T) + 16) + (STATS ? 4 * 2 * t.bn * sizeof(float) : 0);
     if (epi > lds) lds = epi;
+    unsigned nthreads = 256;
 #define YMI_LAUNCH1(KERNEL)                                                                                          \
     do {                                                                                                             \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(KERNEL, grid, dim3(256), lds, stream, P);                                                  \
+        hipLaunchKernelGGL(KERNEL, grid, dim3(nthreads), lds, stream, P);                                             \
     } while (0)
 #define YMI_LAUNCH(BM, BN, WM, WN)                                                              \
     do {                                                                                        \
         if constexpr (std::is_same<T, bf16_t>::value) {                                         \
+            if (spec && spec_ns == 2) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS, true>)); break; } \
+            if (spec) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 3, 8, true, STATS, true>)); break; } \
             if (wide) { YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS>)); break; } \
         }                                                                                       \
         if (fast) YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, true, STATS>));            \

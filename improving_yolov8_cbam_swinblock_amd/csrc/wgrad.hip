@@ -287,6 +287,53 @@ __global__ void wgrad_reduce_small_kernel(const float* __restrict__ slab, int sp
     }
 }
 
+// All pending slab reductions of a backward pass in ONE launch (ymi_wgrad_reduce_batch): a 256-thread workgroup finds its
+// tensor by binary search over the table's first_block column, then sums `lanes` interleaved split chains per output
+// element in a fixed order (deterministic) and scatters into OIHW - the same arithmetic as the per-layer kernels above,
+// without their 73 launch boundaries (each of those kernels was pure latency: 7-12 us for a few hundred KB).
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ymi_wgrad_pending* __restrict__ tab, int n) {
+    __shared__ f32x4 red[256];
+    int lo = 0, hi = n - 1;  // last entry whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_block <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const ymi_wgrad_pending e = tab[lo];
+    // by the end of the backward pass the slabs have left the caches: this kernel streams them from HBM, 16 bytes per
+    // lane and four split chains in flight per lane
+    const int SL = e.lanes, OUTS = 256 / SL;              // OUTS groups of 4 consecutive elements per workgroup
+    const int ol = threadIdx.x % OUTS, lane = threadIdx.x / OUTS;
+    const int64_t el = ((int64_t)((int)blockIdx.x - e.first_block) * OUTS + ol) * 4;  // first element of this lane's group
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    if (el < e.elems) {  // elems is a multiple of 8
+        const float* p = e.slab + el;
+        int k = lane;
+        for (; k + 3 * SL < e.splits; k += 4 * SL) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)k * e.elems);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + SL) * e.elems);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + 2 * SL) * e.elems);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + 3 * SL) * e.elems);
+            s0 += a; s1 += b; s2 += c; s3 += d;
+        }
+        for (; k < e.splits; k += SL) s0 += *reinterpret_cast<const f32x4*>(p + (int64_t)k * e.elems);
+    }
+    red[lane * OUTS + ol] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (lane == 0 && el < e.elems) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < SL; ++q) s += red[q * OUTS + ol];
+        const uint32_t eu = (uint32_t)el;  // < 2^31; the 4 elements share (co, tap): ng and cin are multiples of 4
+        const int co = (int)(eu / (uint32_t)e.ng), col = (int)(eu - (uint32_t)co * (uint32_t)e.ng);
+        const int tap = (int)((uint32_t)col / (uint32_t)e.cin), ci = col - tap * e.cin;
+        if (co < e.cout_real) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (ci + r < e.cin_real) e.dw[((int64_t)co * e.cin_real + ci + r) * e.ntaps + tap] = s[r];
+        }
+    }
+}
+
 constexpr int WG_STAGE_R = 0;
 
 // magic numbers for wg_fast_div
@@ -340,8 +387,56 @@ extern "C" size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, 
     return p.slab_bytes + (size_t)(2048 * 2 + 1) * coutp * sizeof(float) + 256;
 }
 
+static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw, int64_t stride,
+                      float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, ymi_wgrad_pending* pending, void* stream);
+
 extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
                                      int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
+    return wgrad_impl(x, dy, cout_real, cin_real, kh, kw, stride, dw_oihw, dbias, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
+                                              int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
+                                              ymi_wgrad_pending* pending, void* stream) {
+    YMI_CHECK_ARG(pending, "conv2d_bwd_weight_deferred: null pending record");
+    return wgrad_impl(x, dy, cout_real, cin_real, kh, kw, stride, dw_oihw, dbias, workspace, workspace_bytes, pending, stream);
+}
+
+// the records travel to the device table in kernel ARGUMENTS (by value): no host staging buffer, so the launches are
+// graph-capturable (a captured host-to-device copy would re-read its host buffer at replay time)
+constexpr int WG_TABLE_CHUNK = 56;  // 56 x 64 B = 3.5 KB of kernel arguments
+struct WgradTableChunk {
+    ymi_wgrad_pending e[WG_TABLE_CHUNK];
+};
+__global__ void wgrad_table_write_kernel(WgradTableChunk c, int n, ymi_wgrad_pending* __restrict__ table) {
+    const int i = threadIdx.x;
+    if (i < n) table[i] = c.e[i];
+}
+
+extern "C" int ymi_wgrad_reduce_batch(const ymi_wgrad_pending* host_records, int32_t n, ymi_wgrad_pending* device_table, void* stream) {
+    YMI_CHECK_ARG(host_records && device_table && n > 0, "wgrad_reduce_batch: args");
+    hipStream_t s = (hipStream_t)stream;
+    int64_t total = 0;
+    for (int base = 0; base < n; base += WG_TABLE_CHUNK) {
+        WgradTableChunk c{};
+        const int m = n - base < WG_TABLE_CHUNK ? n - base : WG_TABLE_CHUNK;
+        for (int i = 0; i < m; ++i) {
+            c.e[i] = host_records[base + i];
+            YMI_CHECK_ARG(c.e[i].slab && c.e[i].dw && c.e[i].blocks > 0 && (c.e[i].lanes == 4 || c.e[i].lanes == 8 || c.e[i].lanes == 16 || c.e[i].lanes == 32),
+                          "wgrad_reduce_batch: record %d", base + i);
+            c.e[i].first_block = (int32_t)total;
+            total += c.e[i].blocks;
+        }
+        hipLaunchKernelGGL(wgrad_table_write_kernel, dim3(1), dim3(64), 0, s, c, m, device_table + base);
+    }
+    YMI_CHECK_ARG(total < (1ll << 31), "wgrad_reduce_batch: too many workgroups");
+    hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)total), dim3(256), 0, s, (const ymi_wgrad_pending*)device_table, (int)n);
+    YMI_CHECK_LAUNCH("wgrad_reduce_batch");
+    return YMI_OK;
+}
+
+static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw, int64_t stride,
+                      float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, ymi_wgrad_pending* pending, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(dy) && dw_oihw && workspace, "conv2d_bwd_weight: bad argument");
     YMI_CHECK_ARG(x->dtype == dy->dtype, "conv2d_bwd_weight: dtype mismatch");
     const int ch = x->dtype == YMI_BF16 ? 8 : 4;
@@ -402,7 +497,11 @@ extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, 
     ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");
     const int64_t elems = (int64_t)a.CoutP * a.NG;
-    if (p.splits > 32) {
+    if (pending) {  // the slab sum is left to ymi_wgrad_reduce_batch (one launch for every layer of the backward pass)
+        const int lanes = p.splits > 128 ? 32 : p.splits > 32 ? 16 : p.splits > 8 ? 8 : 4;
+        *pending = ymi_wgrad_pending{a.slab, dw_oihw, elems, p.splits, a.NG, a.Cin, (int32_t)cout_real, (int32_t)cin_real, (int32_t)(kh * kw), lanes, 0,
+                                     (int32_t)((elems / 4 + 256 / lanes - 1) / (256 / lanes))};
+    } else if (p.splits > 32) {
 #define YMI_WRED(SL) hipLaunchKernelGGL(wgrad_reduce_kernel<SL>, dim3((unsigned)((elems + 1024 / SL - 1) / (1024 / SL))), dim3(1024), 0, s, (const float*)a.slab, \
                                         p.splits, a.CoutP, a.NG, a.Cin, (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw)
         if (p.splits <= 64) YMI_WRED(8);

@@ -104,6 +104,12 @@ class GradientBuckets:
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params] if (world_size > 1 and overlap) else []
+        if self._hooks and params and params[0].is_cuda:
+            from .. import ops
+
+            # the hooks read gradients DURING backward: every weight gradient must be complete when its hook fires, so the
+            # end-of-pass batched slab sum (ops._flush_wgrads) cannot be used with this schedule
+            ops.set_wgrad_deferred(False)
 
     def _launch(self, bi, grads=None):
         """pack the bucket's gradients into its flat buffer (one multi-tensor copy) and start the all-reduce."""

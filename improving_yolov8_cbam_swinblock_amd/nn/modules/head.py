@@ -68,12 +68,16 @@ class Detect(nn.Module):
 
     def forward(self, x):
         x = list(x)
+        box, cls = [], []
         for i in range(self.nl):
             xi = ops.to_internal(x[i])
-            x[i] = ops.concat([self.cv2[i](xi), self.cv3[i](xi)])
+            box.append(self.cv2[i](xi))
+            cls.append(self.cv3[i](xi))
+            x[i] = ops.concat([box[i], cls[i]])
         if self.training:
             return x
-        y = self._inference(x)
+        y = self._inference(box, cls)  # decoded from the branch outputs (16-byte aligned rows), not from the odd-width concat
+        self.shape = x[0].shape
         return y if self.export else (y, x)
 
     def forward_split(self, x):
@@ -86,14 +90,16 @@ class Detect(nn.Module):
             cls.append(self.cv3[i](xi))
         return box, cls
 
-    def _inference(self, x):
+    def _inference(self, box, cls=None):
         """reference head.py:103-142, non-export branch: DFL expectation, anchor decode, stride scale and class sigmoid in
-        one HIP launch over the Detect maps (csrc/loss.hip infer_decode_kernel) -> [B, 4+nc, A] float32."""
+        one HIP launch over the Detect maps (csrc/loss.hip infer_decode_kernel) -> [B, 4+nc, A] float32.
+        box / cls: per-level branch outputs; or, as in the reference, one list of concatenated [B, no, H, W] maps."""
         if self.reg_max != 16:
             raise NotImplementedError("the decode kernel is built for reg_max = 16")
-        box = [xi[:, : self.reg_max * 4] for xi in x]
-        cls = [xi[:, self.reg_max * 4 :] for xi in x]
-        self.shape = x[0].shape
+        if cls is None:  # reference signature: split the concatenated maps (a copy when their rows are not 16-byte aligned)
+            maps = [ops.to_internal(t) for t in box]
+            box = [t[:, : self.reg_max * 4].contiguous(memory_format=torch.channels_last) for t in maps]
+            cls = [t[:, self.reg_max * 4 :].contiguous(memory_format=torch.channels_last) for t in maps]
         if getattr(self, "_stride_host", None) is None or len(self._stride_host) != self.nl:
             self._stride_host = [float(s) for s in self.stride]  # one device->host read, not one per call
         return ops.detect_decode(box, cls, self._stride_host)

@@ -245,6 +245,8 @@ def _conv_out_hw(h, w, k, s):
 
 def _wgrad(x, dy, cout, cin, k, stride, want_bias):
     """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None)"""
+    if _deferred["on"] and _in_backward():
+        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias)
     dev = x.device
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
     db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
@@ -253,6 +255,14 @@ def _wgrad(x, dy, cout, cin, k, stride, want_bias):
     ws = workspace(need, dev, "wgrad")
     check(L().ymi_conv2d_bwd_weight(_byref(tx), _byref(ty), cout, cin, k, k, stride, ptr(dw), ptr(db), ptr(ws), ws.numel(), stream_ptr()), "conv2d_bwd_weight")
     return dw, db
+
+
+def _in_backward():
+    """True inside an autograd backward pass (where the engine accepts end-of-pass callbacks)."""
+    try:
+        return torch._C._current_graph_task_id() != -1
+    except AttributeError:  # very old torch: no way to tell, never defer
+        return False
 
 
 # ---- weight gradients on a second stream ------------------------------------------------------------------------
@@ -308,6 +318,57 @@ def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias):
     _async["keep"].append((x, dy))
     _async["pending"] = True
     return out
+
+
+# ---- slab sums of ALL weight gradients of a backward pass in one launch ---------------------------------------------
+# Inside a backward pass every weight-gradient GEMM leaves its split-K slabs un-summed and registers a record; a callback
+# the autograd engine runs when the pass ends (before backward() returns) sums them all with ONE launch
+# (ymi_wgrad_reduce_batch).  Until then the returned dW tensors hold no data: nothing reads a gradient before the pass is
+# over, EXCEPT post-accumulate-grad hooks (the overlapped DDP schedule) - engine/ddp.py switches the deferral off there.
+_deferred = {"on": True, "records": [], "keep": [], "queued": False, "table": None}
+
+
+def set_wgrad_deferred(flag):
+    _deferred["on"] = bool(flag)
+
+
+def _flush_wgrads():
+    recs, keep = _deferred["records"], _deferred["keep"]
+    _deferred["records"], _deferred["keep"], _deferred["queued"] = [], [], False
+    if not recs:
+        return
+    dev = keep[0][0].device
+    n = len(recs)
+    tab = _deferred["table"]
+    if tab is None or tab.device != dev or tab.numel() < n * ctypes.sizeof(_lib.WgradPending):
+        tab = _deferred["table"] = torch.empty(max(n, 128) * ctypes.sizeof(_lib.WgradPending), dtype=torch.uint8, device=dev)
+    arr = (_lib.WgradPending * n)(*recs)
+    if _async["on"]:  # the GEMMs ran on the side stream: the sum follows them there (joined by async_wgrad's exit)
+        with torch.cuda.stream(_side_stream(dev)):
+            check(L().ymi_wgrad_reduce_batch(arr, n, ptr(tab), stream_ptr()), "wgrad_reduce_batch")
+        _async["pending"] = True
+    else:
+        check(L().ymi_wgrad_reduce_batch(arr, n, ptr(tab), stream_ptr()), "wgrad_reduce_batch")
+    del keep
+
+
+def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias):
+    """as _wgrad, with the slab sum left to the end of the backward pass.  The slabs stay alive in _deferred['keep']."""
+    dev = x.device
+    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
+    db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
+    ty, tx = as_ymi(dy), as_ymi(x)
+    need = L().ymi_conv2d_bwd_weight_workspace(ty.n * ty.h * ty.w, ty.c, tx.c, k, k)
+    ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
+    rec = _lib.WgradPending()
+    check(L().ymi_conv2d_bwd_weight_deferred(_byref(tx), _byref(ty), cout, cin, k, k, stride, ptr(dw), ptr(db), ptr(ws), ws.numel(), _byref(rec), stream_ptr()),
+          "conv2d_bwd_weight")
+    _deferred["records"].append(rec)
+    _deferred["keep"].append((ws, x, dy))
+    if not _deferred["queued"]:
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+        _deferred["queued"] = True
+    return dw, db
 
 
 class GradJoin:

@@ -161,6 +161,24 @@ int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, in
 int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
                           int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, void* stream);
 size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, int64_t cin, int64_t kh, int64_t kw);
+/* The same GEMM with the ordered slab sum DEFERRED: `pending` (host memory) receives what ymi_wgrad_reduce_batch needs.
+ * The caller keeps `workspace` (the slabs) alive until that launch.  One reduce launch then serves every layer of a
+ * backward pass (the 73 per-layer reduce launches of YOLOv8s were pure latency). */
+typedef struct ymi_wgrad_pending {
+    const float* slab;   /* [splits][elems] */
+    float* dw;           /* OIHW destination */
+    int64_t elems;       /* padded Cout * (taps * padded Cin) */
+    int32_t splits, ng, cin, cout_real, cin_real, ntaps;
+    int32_t lanes;       /* interleaved split chains per output element (4, 8, 16 or 32) */
+    int32_t first_block; /* set by ymi_wgrad_reduce_batch */
+    int32_t blocks;      /* workgroups this record needs: ceil(elems / 4 / (256 / lanes)) */
+} ymi_wgrad_pending;
+int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
+                                   int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
+                                   ymi_wgrad_pending* pending, void* stream);
+/* host_records: the n records of the pending layers (HOST memory; first_block is filled in here); device_table: device
+ * scratch for n records.  The records reach the device inside kernel arguments (no host staging: graph-capturable). */
+int ymi_wgrad_reduce_batch(const ymi_wgrad_pending* host_records, int32_t n, ymi_wgrad_pending* device_table, void* stream);
 
 /* -------------------------------------------------------------------- SPPF pooling cascade ---- */
 
