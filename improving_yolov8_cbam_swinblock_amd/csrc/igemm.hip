@@ -80,18 +80,41 @@ template <> struct Mma<bf16_t> {
         constexpr int ROWB = CPR * 16;
         const int l15 = lane & 15, l4 = lane >> 4;
         const int sw = CPR == 4 ? ((-(l15 >> 2)) & 3) : ((l15 >> 1) & 7);
+        // Every fragment of the K step is requested before the first MFMA, and each 32-deep sub-step waits only for ITS
+        // reads (counted lgkmcnt): the second sub-step's reads travel while the first multiplies.  hipcc schedules LDS
+        // reads next to their uses and always waits with lgkmcnt(0) here (one exposed LDS round trip per 4-8 MFMAs; PMC,
+        // profiles/r02_pmc_igemm.txt: waves parked 39 % of their cycles), so the reads and waits are written out.
+        constexpr int KS = CPR / 4;
+        static_assert(KS <= 2, "one or two 32-deep sub-steps");
+        bf16x8 wf[KS][TN], xf[KS][TM];
+        const uint32_t bbase = (uint32_t)(uintptr_t)(lptr_t)(Bs + (b_row0 + l15) * ROWB);
+        const uint32_t abase = (uint32_t)(uintptr_t)(lptr_t)(As + (a_row0 + l15) * ROWB);
 #pragma unroll
-        for (int ks = 0; ks < CPR / 4; ++ks) {
-            const int coff = (((4 * ks + l4) ^ sw) << 4);
-            bf16x8 wf[TN], xf[TM];
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint32_t coff = (uint32_t)(((4 * ks + l4) ^ sw) << 4);
 #pragma unroll
-            for (int tn = 0; tn < TN; ++tn) wf[tn] = *reinterpret_cast<const bf16x8*>(Bs + (b_row0 + tn * 16 + l15) * ROWB + coff);
+            for (int tn = 0; tn < TN; ++tn)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[ks][tn]) : "v"(bbase + coff), "n"(tn * 16 * ROWB));
 #pragma unroll
-            for (int tm = 0; tm < TM; ++tm) xf[tm] = *reinterpret_cast<const bf16x8*>(As + (a_row0 + tm * 16 + l15) * ROWB + coff);
+            for (int tm = 0; tm < TM; ++tm)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[ks][tm]) : "v"(abase + coff), "n"(tm * 16 * ROWB));
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            // wait for sub-step ks: the (KS-1-ks)*(TN+TM) younger reads may still be in flight.  The fragments are tied
+            // to the wait as in/out operands so that no MFMA of this sub-step is scheduled above it.
+            __builtin_amdgcn_sched_barrier(0);  // the MFMAs of the previous sub-step stay above this wait
+            if (ks + 1 < KS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");  // (TN + TM <= 8: fits the 4-bit counter)
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(wf[ks][tn]));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(xf[ks][tm]));
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tn], xf[tm], acc[tn][tm], 0, 0, 0);
+                for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 };
@@ -124,24 +147,27 @@ template <> struct Mma<float> {
 // piece issue cost): 8 pieces per K step on the multiplying waves cost more than their 32 MFMAs (512 cycles) - the
 // reason ring depth never helped the unspecialised kernel.  Each SIMD now holds one multiplying and one loading wave
 // of the workgroup; the two roles meet at ONE barrier per K step.
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false>
-__global__ __launch_bounds__(SPEC ? 512 : 256) void igemm_kernel(IgemmMulti P) {
+// NTHR = 512 without SPEC: eight waves that all load and multiply (256x128 tiles in a 4x2 wave grid of 64x64 wave tiles:
+// 0.75x the operand bytes per FLOP of the 128x128 tile at the same registers per wave).
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false, int NTHR = (SPEC ? 512 : 256)>
+__global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int ROWB = CPR * 16;                    // bytes per LDS row = K step per row (64: 32 bf16 / 16 f32; 128: 64 bf16)
-    constexpr int RPI = 256 / CPR, RPW = 64 / CPR;    // rows filled per block-wide / per wave load instruction
-    constexpr int NA = (BM * CPR + 255) / 256, NB = (BN * CPR + 255) / 256;
+    constexpr int LT = SPEC ? 256 : NTHR;             // threads that issue loads
+    constexpr int RPI = LT / CPR, RPW = 64 / CPR;     // rows filled per block-wide / per wave load instruction
+    constexpr int NA = (BM * CPR + LT - 1) / LT, NB = (BN * CPR + LT - 1) / LT;
     constexpr int STAGE = (BM + BN) * ROWB;
     static_assert(CPR == 4 || (CPR == 8 && FAST), "128-byte rows need tap-uniform K steps");
-    static_assert(WM * WN == 4, "4 waves");
-    static_assert(BM % 64 == 0, "every wave issues all A loads");
+    static_assert(WM * WN == (SPEC ? 4 : NTHR / 64), "one wave tile per multiplying wave");
+    static_assert((BM * CPR) % LT == 0, "every loading wave issues all A loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
-    constexpr int NT = SPEC ? 512 : 256;
+    constexpr int NT = NTHR;
     const int tid_all = threadIdx.x, lane = tid_all & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);  // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
     const bool loader = !SPEC || wave_all >= 4, consumer = !SPEC || wave_all < 4;
-    const int tid = tid_all & 255, wave = wave_all & 3;  // index inside the role's four waves
+    const int tid = SPEC ? (tid_all & 255) : tid_all, wave = SPEC ? (wave_all & 3) : wave_all;  // index inside the role's waves
     const int wm = wave / WN, wn = wave % WN;
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id & 7), each with its own L2.  Every XCD gets a
     // CONTIGUOUS range of M blocks (neighbouring pixel tiles share 3x3 halo rows) and walks the N blocks of one M block
@@ -231,13 +257,13 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void igemm_kernel(IgemmMulti P) {
         if constexpr (FAST) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[i], (lptr_t)(As + (i * LT + wave * 64) * 16), 16, 0, 0);
                 a_ptr[i] += a_inc[i];
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if ((wave * RPW + RPI * j) < BN) {  // wave-uniform
-                    __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[j], (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[j], (lptr_t)(Bs + (j * LT + wave * 64) * 16), 16, 0, 0);
                     b_ptr[j] += b_inc[j];
                 }
             }
@@ -254,14 +280,14 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void igemm_kernel(IgemmMulti P) {
                 const int hi = a_h[i] + dh, wi = a_w[i] + dw;
                 const bool ok = a_ok[i] && kvalid && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
                 const T* src = ok ? xg + ((int64_t)(a_nH[i] + hi) * a.W + wi) * a.ldx + cic * CH : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * 256 + wave * 64) * 16), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(As + (i * LT + wave * 64) * 16), 16, 0, 0);
             }
 #pragma unroll
             for (int j = 0; j < NB; ++j) {
                 if ((wave * RPW + RPI * j) < BN) {  // wave-uniform
                     const bool ok = b_ok[j] && kvalid;
                     const T* src = ok ? b_ptr[j] + (int64_t)(tap * a.cpt + cic) * CH : zero;
-                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * LT + wave * 64) * 16), 16, 0, 0);
                 }
             }
             cic += adv_c;
@@ -284,6 +310,15 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void igemm_kernel(IgemmMulti P) {
     constexpr int LPT_AONLY = NA;  // waves beyond the B tile's rows (BN < 64) issue no B loads
     const bool b_wave = (BN >= RPI) || (wave * RPW < BN);
     const int nkt = (a.KC + CPR - 1) / CPR;
+    if constexpr (NS == 1) {
+        // single LDS stage: no overlap inside a workgroup, half the LDS, so twice the resident workgroups overlap each other
+        for (int kt = 0; kt < nkt; ++kt) {
+            issue(0);
+            wait_vmcnt_barrier<0>();
+            Mma<T>::template step<TM, TN, CPR>(smem, smem + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
+            asm volatile("s_barrier" ::: "memory");  // everyone has read the stage before it is refilled
+        }
+    } else {
     if (loader) {
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
@@ -307,6 +342,7 @@ __global__ __launch_bounds__(SPEC ? 512 : 256) void igemm_kernel(IgemmMulti P) {
             const char* As = smem + (kt % NS) * STAGE;
             Mma<T>::template step<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
         }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
 
@@ -451,8 +487,9 @@ struct TileChoice {
 // Largest tile that still yields ~1.5 workgroups per CU (measured on the 40x40 / 20x20 layers of the model: 400 tiles of
 // 128x128 beat 800 of 64x128 by 25-30 %, and below that 128x64, then 64x64, win); short-K GEMMs (K <= 384) are
 // prologue/epilogue-dominated and run best as 128x64 (three resident workgroups per CU).
-static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats) {
+static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats, bool bf16 = true) {
     (void)stats;
+    const bool stats_bf16_hint = bf16;  // the 256x128 tile exists for bf16 only
     TileChoice t;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((cout + bn - 1) / bn); };
     static const int enough_env = getenv("YMI_IGEMM_ENOUGH") ? atoi(getenv("YMI_IGEMM_ENOUGH")) : 400;  // tuning knob
@@ -469,6 +506,11 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats)
         t.bm = 128; t.bn = 64;
     } else {
         t.bm = 64; t.bn = 64;
+    }
+    // 256x128 (eight waves): only where it still leaves >= `big_env` workgroups and operand rows are 128 bytes
+    static const int big_env = getenv("YMI_IGEMM_BIG") ? atoi(getenv("YMI_IGEMM_BIG")) : 0;  // 0: off (measured 5-30 % SLOWER wherever it applies: profiles/r02_conv_bench_big.txt)
+    if (big_env > 0 && stats_bf16_hint && cout >= 128 && ktot % 64 == 0 && blocks(256, 128) >= big_env) {
+        t.bm = 256; t.bn = 128;
     }
     static const char* tile_env = getenv("YMI_IGEMM_TILE");  // "bm,bn": force a tile (tuning knob)
     if (tile_env) {
@@ -508,6 +550,7 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     const size_t epi = (size_t)t.bm * (t.bn * sizeof(T) + 16) + (STATS ? 4 * 2 * t.bn * sizeof(float) : 0);
     if (epi > lds) lds = epi;
     unsigned nthreads = 256;
+    static const int ns_env = getenv("YMI_IGEMM_NS") ? atoi(getenv("YMI_IGEMM_NS")) : 2;  // LDS ring depth of the 128-byte-row kernels (tuning knob)
 #define YMI_LAUNCH1(KERNEL)                                                                                          \
     do {                                                                                                             \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
@@ -518,12 +561,25 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
         if constexpr (std::is_same<T, bf16_t>::value) {                                         \
             if (spec && spec_ns == 2) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS, true>)); break; } \
             if (spec) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 3, 8, true, STATS, true>)); break; } \
+            if (wide && ns_env == 1) { lds = (size_t)(t.bm + t.bn) * 128 > epi ? (size_t)(t.bm + t.bn) * 128 : epi; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 1, 8, true, STATS>)); break; } \
+            if (wide && ns_env == 3) { lds = (size_t)3 * (t.bm + t.bn) * 128 > epi ? (size_t)3 * (t.bm + t.bn) * 128 : epi; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 3, 8, true, STATS>)); break; } \
             if (wide) { YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS>)); break; } \
         }                                                                                       \
         if (fast) YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, true, STATS>));            \
         else YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, false, STATS>));                \
     } while (0)
-    if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2);
+    if (t.bm == 256 && t.bn == 128) {
+        if constexpr (std::is_same<T, bf16_t>::value) {
+            YMI_CHECK_ARG(wide, "igemm: the 256x128 tile needs 128-byte operand rows");
+            nthreads = 512;
+            lds = (size_t)2 * (256 + 128) * 128;
+            if (epi > lds) lds = epi;
+            YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 2, 8, true, STATS, false, 512>));
+        } else {
+            ymi_set_error("igemm: the 256x128 tile is bf16 only");
+            return YMI_EINVAL;
+        }
+    } else if (t.bm == 128 && t.bn == 128) YMI_LAUNCH(128, 128, 2, 2);
     else if (t.bm == 128 && t.bn == 64) YMI_LAUNCH(128, 64, 2, 2);
     else if (t.bm == 128 && t.bn == 32) YMI_LAUNCH(128, 32, 4, 1);
     else if (t.bm == 64 && t.bn == 128) YMI_LAUNCH(64, 128, 2, 2);
@@ -550,7 +606,7 @@ static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats,
         mmax = arr[i].M > mmax ? arr[i].M : mmax;
         kmax = arr[i].ktot > kmax ? arr[i].ktot : kmax;
     }
-    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout, kmax, stats);
+    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout, kmax, stats, dtype == YMI_BF16);
     if (host_blocks) *host_blocks = (arr[0].M + t.bm - 1) / t.bm;
     int prof = -1;
     if (ymi_prof_enabled()) {
