@@ -141,6 +141,142 @@ template <> struct Mma<float> {
 };
 
 
+// ---- epilogue shared by the GEMM kernels -------------------------------------------------------------------------
+// The tile leaves through LDS: lanes drop their 4-channel groups into a [pixel][channel] image, then the workgroup
+// stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines (per-lane 8-byte stores
+// to 16 different rows cost 2-3x the time of the same bytes stored this way).  STATS: raw output + deterministic
+// per-block BatchNorm partial sums; otherwise scale / bias / activation / up to two addends.
+template <typename T, int BM, int BN, int WM, int WN, bool STATS, int NT>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], char* smem, int m0, int n0, int mb, int wm,
+                                               int wn, int lane, int tid_all, bool consumer) {
+    constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
+    const int l15 = lane & 15, l4 = lane >> 4;
+    T* yg = reinterpret_cast<T*>(a.y);
+    constexpr int ES = (int)sizeof(T);
+    constexpr int CROW = BN * ES + 16;  // padded LDS row of the output image
+    char* Cimg = smem;
+    float* red = reinterpret_cast<float*>(smem + BM * CROW);  // [WM][2][BN] (STATS)
+    const T* rg = reinterpret_cast<const T*>(a.res);    // (no __restrict__: an addend may be the output buffer itself, read before it is written)
+    const T* rg2 = reinterpret_cast<const T*>(a.res2);
+
+    // output pixel (row of y, and of the epilogue addends) that GEMM row m produces
+    auto out_pixel = [&](int m) -> int64_t {
+        if (a.s_out == 1 && a.Hy == a.Ho && a.Wy == a.Wo) return (int64_t)m;
+        const int t = fast_div(m, a.wo_mul, a.wo_shr, a.Wo);
+        const int wo = m - t * a.Wo;
+        const int n = fast_div(t, a.ho_mul, a.ho_shr, a.Ho);
+        const int ho = t - n * a.Ho;
+        return ((int64_t)n * a.Hy + ho * a.s_out + a.oh_off) * a.Wy + wo * a.s_out + a.ow_off;
+    };
+    auto out_offset = [&](int m) -> int64_t { return out_pixel(m) * a.ldy; };
+
+    if (consumer) {
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int chl = (wn * TN + tn) * 16 + 4 * l4;  // channel within the block tile
+        const int ch = n0 + chl;
+        float sc[4], bi[4];
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        if constexpr (!STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool cok = ch + r < a.Cout;
+                sc[r] = (a.scale && cok) ? a.scale[ch + r] : 1.0f;
+                bi[r] = (a.bias && cok) ? a.bias[ch + r] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int row = (wm * TM + tm) * 16 + l15;
+            const int m = m0 + row;
+            float v[4];
+            if constexpr (STATS) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = to_f32(from_f32<T>(acc[tn][tm][r]));  // statistics of what is stored
+                    s1[r] += v[r];
+                    s2[r] += v[r] * v[r];
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(acc[tn][tm][r] * sc[r] + bi[r], a.act);
+                if (rg && m < a.M) {
+                    const int64_t px = out_pixel(m);
+                    if (a.vec_store && ch + 3 < a.Cout) {
+                        float rr[4];
+                        Pack<T, 4>::load(rg + px * a.ldres + ch, rr);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                        if (rg2) {
+                            Pack<T, 4>::load(rg2 + px * a.ldres2 + ch, rr);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                        }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (ch + r < a.Cout) v[r] += to_f32(rg[px * a.ldres + ch + r]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch + r]) : 0.f);
+                    }
+                }
+            }
+            if (a.vec16) {
+                Pack<T, 4>::store(reinterpret_cast<T*>(Cimg + row * CROW) + chl, v);
+            } else if (m < a.M) {  // unaligned / odd channel counts: direct stores
+                const int64_t yo = out_offset(m);
+                if (a.vec_store && ch + 3 < a.Cout) {
+                    Pack<T, 4>::store(yg + yo + ch, v);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (ch + r < a.Cout) yg[yo + ch + r] = from_f32<T>(v[r]);
+                }
+            }
+        }
+        if constexpr (STATS) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s1[r] += __shfl_xor(s1[r], o, 64);
+                    s2[r] += __shfl_xor(s2[r], o, 64);
+                }
+            }
+            if (l15 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    red[(wm * 2 + 0) * BN + chl + r] = s1[r];
+                    red[(wm * 2 + 1) * BN + chl + r] = s2[r];
+                }
+            }
+        }
+    }
+    }  // consumer
+    __syncthreads();
+    if constexpr (STATS) {
+        if (tid_all < 2 * BN) {
+            const int which = tid_all / BN, chl = tid_all % BN;
+            float sum = 0.f;
+#pragma unroll
+            for (int q = 0; q < WM; ++q) sum += red[(q * 2 + which) * BN + chl];
+            const int ch = n0 + chl;
+            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.Cout + ch] = sum;
+        }
+    }
+    if (a.vec16) {
+        constexpr int CPW = BN * ES / 16;  // 16-byte chunks per output row
+        constexpr int EPC = 16 / ES;       // elements per chunk
+#pragma unroll 4
+        for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
+            const int row = idx / CPW, cc = idx % CPW;
+            const int m = m0 + row, ch = n0 + cc * EPC;
+            if (m < a.M && ch < a.Cout) {
+                const u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
+                *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
+            }
+        }
+    }
+}
+
 // SPEC: wave specialisation.  512-thread workgroup: waves 0-3 multiply (LDS fragment reads + MFMA, the same 2x2 wave grid),
 // waves 4-7 only load (address generation + LDS-DMA into an NS-deep ring, counted vmcnt).  An LDS-DMA piece costs its
 // issuing wave 100-185 cycles inside a phase that also carries fragment reads and MFMAs (MI355X_MICROARCH.md, LDS-DMA
@@ -350,131 +486,140 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     // The tile leaves through LDS: lanes drop their 4-channel groups into a [pixel][channel] image, then the
     // workgroup stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines
     // (per-lane 8-byte stores to 16 different rows cost 2-3x the time of the same bytes stored this way).
+    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer);
+}
+
+// ---- 3x3 stride-1 convolution (forward and data gradient) with the input rows of the tile resident in LDS ---------------
+// The GEMM kernel above fetches the A operand once per TAP: nine 16 KB tiles per 64 input channels, although the nine
+// tiles of a 128-pixel block are the same ~130+2W pixels shifted by (dh*W + dw) rows.  All variants of that kernel run
+// at the same speed whatever the ring depth, occupancy, wave roles or fragment scheduling (profiles/r02_conv_bench_*.txt):
+// what they share is the byte count through the L2 -> LDS path.  Here the 128 + 2(W+1) pixel rows a block needs are
+// loaded ONCE per 64-channel chunk (an "image" in LDS) and every tap reads its fragments from the image at a shifted row;
+// only the weight tile is fetched per tap.  Bytes per chunk: (128 + 2W + 2) * 128 + 9 * BN * 128 instead of
+// 9 * (128 + BN) * 128 (W = 40, BN = 128: 174 KB vs 295 KB).
+// Shifted rows cross image-row and image boundaries (the left neighbour of pixel (y, 0) is pixel (y-1, W-1) in linear
+// order), so each lane zeroes its activation fragment for the taps its pixel does not have (4 v_cndmask per fragment).
+template <int BN, int CPR, bool STATS>
+__global__ __launch_bounds__(256) void conv3_kernel(IgemmArgs a, int R, int a_bytes) {
+    typedef bf16_t T;
+    constexpr int BM = 128, WM = 2, WN = 2, TM = 4, TN = BN / WN / 16;
+    constexpr int ROWB = CPR * 16, KCH = CPR * 8;      // bytes / channels of one LDS row (one chunk of input channels)
+    constexpr int RPI = 256 / CPR;                      // rows filled per block-wide load instruction
+    constexpr int NB = (BN * CPR + 255) / 256;
+    constexpr int KS = CPR / 4;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Aimg = smem;
+    char* Bst = smem + a_bytes;  // [2][BN][ROWB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
     const int l15 = lane & 15, l4 = lane >> 4;
-    T* yg = reinterpret_cast<T*>(a.y);
-    constexpr int ES = (int)sizeof(T);
-    constexpr int CROW = BN * ES + 16;  // padded LDS row of the output image
-    char* Cimg = smem;
-    float* red = reinterpret_cast<float*>(smem + BM * CROW);  // [WM][2][BN] (STATS)
-    const T* rg = reinterpret_cast<const T*>(a.res);    // (no __restrict__: an addend may be the output buffer itself, read before it is written)
-    const T* rg2 = reinterpret_cast<const T*>(a.res2);
+    const int orig = blockIdx.x, xcd = orig & 7, seq = orig >> 3;
+    const int nb = seq % a.nnb, ml = seq / a.nnb;
+    const int mb = xcd * a.mpx + ml;
+    if (mb >= a.nmb) return;
+    const int m0 = mb * BM, n0 = nb * BN;
+    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
+    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
+    const T* zero = reinterpret_cast<const T*>(a.zero);
+    const int W = a.W, halo = W + 1;
+    const int Cin = a.cpt * 8;
 
-    // output pixel (row of y, and of the epilogue addends) that GEMM row m produces
-    auto out_pixel = [&](int m) -> int64_t {
-        if (a.s_out == 1 && a.Hy == a.Ho && a.Wy == a.Wo) return (int64_t)m;
-        const int t = fast_div(m, a.wo_mul, a.wo_shr, a.Wo);
-        const int wo = m - t * a.Wo;
-        const int n = fast_div(t, a.ho_mul, a.ho_shr, a.Ho);
-        const int ho = t - n * a.Ho;
-        return ((int64_t)n * a.Hy + ho * a.s_out + a.oh_off) * a.Wy + wo * a.s_out + a.ow_off;
+    // ---- loader state: this thread's chunk column and rows -----------------------------------------------------------
+    const int lrow = tid / CPR;
+    const int csrc = CPR == 4 ? ((tid & 3) ^ ((-(lrow >> 2)) & 3)) : ((tid & 7) ^ ((lrow >> 1) & 7));  // swizzle is invariant under row += RPI
+    const int nai = (R * CPR + 255) / 256;
+    const T* b_row[NB];
+    bool b_ok[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int rn = lrow + RPI * j, n = n0 + rn;
+        b_ok[j] = n < a.Cout && rn < BN;
+        b_row[j] = wg + (int64_t)(b_ok[j] ? n : 0) * a.ktot + csrc * 8;
+    }
+    auto issue_a = [&](int cin0) {
+        for (int i = 0; i < nai; ++i) {
+            const int row = lrow + RPI * i;
+            const int64_t p = (int64_t)m0 - halo + row;
+            const bool ok = row < R && p >= 0 && p < a.M;
+            const T* src = ok ? xg + p * a.ldx + cin0 + csrc * 8 : zero;
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Aimg + (i * 256 + wave * 64) * 16), 16, 0, 0);
+        }
     };
-    auto out_offset = [&](int m) -> int64_t { return out_pixel(m) * a.ldy; };
+    auto issue_b = [&](int stage, int tap, int cin0) {
+        char* Bs = Bst + stage * (BN * ROWB);
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if ((wave * (64 / CPR) + RPI * j) < BN) {  // wave-uniform
+                const T* src = b_ok[j] ? b_row[j] + tap * Cin + cin0 : zero;
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+        }
+    };
 
-    if (consumer) {
+    // ---- consumer state: per pixel tile of this lane, which taps its pixel lacks -------------------------------------
+    int flags[TM];
 #pragma unroll
-    for (int tn = 0; tn < TN; ++tn) {
-        const int chl = (wn * TN + tn) * 16 + 4 * l4;  // channel within the block tile
-        const int ch = n0 + chl;
-        float sc[4], bi[4];
-        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
-        if constexpr (!STATS) {
+    for (int tm = 0; tm < TM; ++tm) {
+        const int m = m0 + wm * 64 + tm * 16 + l15;
+        const int mm = m < a.M ? m : 0;
+        const int t = fast_div(mm, a.wo_mul, a.wo_shr, a.Wo);
+        const int x = mm - t * a.Wo;
+        const int n = fast_div(t, a.ho_mul, a.ho_shr, a.Ho);
+        const int y = t - n * a.Ho;
+        flags[tm] = (x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == a.H - 1 ? 8 : 0) | (m < a.M ? 0 : 16);
+    }
+    const int swb = CPR == 4 ? ((-(l15 >> 2)) & 3) : ((l15 >> 1) & 7);  // weight tile: fragment rows start at multiples of 16
+    f32x4 acc[TN][TM];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const bool cok = ch + r < a.Cout;
-                sc[r] = (a.scale && cok) ? a.scale[ch + r] : 1.0f;
-                bi[r] = (a.bias && cok) ? a.bias[ch + r] : 0.0f;
-            }
-        }
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-            const int row = (wm * TM + tm) * 16 + l15;
-            const int m = m0 + row;
-            float v[4];
-            if constexpr (STATS) {
+        for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nchunks = a.cpt / CPR;
+    for (int ck = 0; ck < nchunks; ++ck) {
+        const int cin0 = ck * KCH;
+        if (ck > 0) asm volatile("s_barrier" ::: "memory");  // every wave has finished reading the previous chunk's image and weight tiles
+        issue_a(cin0);
+        issue_b(0, 0, cin0);
+        for (int tap = 0; tap < a.ntaps; ++tap) {
+            wait_vmcnt_barrier<0>();  // this tap's weight tile (and, at tap 0, the image) has landed; nobody still reads the other stage
+            if (tap + 1 < a.ntaps) issue_b((tap + 1) & 1, tap + 1, cin0);
+            const int dh = (int)((a.tap_dh >> (4 * tap)) & 15) - 8;
+            const int dw = (int)((a.tap_dw >> (4 * tap)) & 15) - 8;
+            const int tapmask = (dw < 0 ? 1 : 0) | (dw > 0 ? 2 : 0) | (dh < 0 ? 4 : 0) | (dh > 0 ? 8 : 0) | 16;
+            const int shift = halo + dh * W + dw + wm * 64 + l15;  // image row of this lane's pixel for pixel tile 0
+            const char* Bs = Bst + (tap & 1) * (BN * ROWB);
+            bf16x8 wf[KS][TN], xf[KS][TM];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v[r] = to_f32(from_f32<T>(acc[tn][tm][r]));  // statistics of what is stored
-                    s1[r] += v[r];
-                    s2[r] += v[r] * v[r];
-                }
-            } else {
+            for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(acc[tn][tm][r] * sc[r] + bi[r], a.act);
-                if (rg && m < a.M) {
-                    const int64_t px = out_pixel(m);
-                    if (a.vec_store && ch + 3 < a.Cout) {
-                        float rr[4];
-                        Pack<T, 4>::load(rg + px * a.ldres + ch, rr);
+                for (int tn = 0; tn < TN; ++tn)
+                    wf[ks][tn] = *reinterpret_cast<const bf16x8*>(Bs + (wn * TN * 16 + tn * 16 + l15) * ROWB + (((4 * ks + l4) ^ swb) << 4));
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                        if (rg2) {
-                            Pack<T, 4>::load(rg2 + px * a.ldres2 + ch, rr);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (ch + r < a.Cout) v[r] += to_f32(rg[px * a.ldres + ch + r]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch + r]) : 0.f);
-                    }
+                for (int tm = 0; tm < TM; ++tm) {
+                    const int row = shift + tm * 16;
+                    const int sw = CPR == 4 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7);
+                    xf[ks][tm] = *reinterpret_cast<const bf16x8*>(Aimg + row * ROWB + (((4 * ks + l4) ^ sw) << 4));
                 }
             }
-            if (a.vec16) {
-                Pack<T, 4>::store(reinterpret_cast<T*>(Cimg + row * CROW) + chl, v);
-            } else if (m < a.M) {  // unaligned / odd channel counts: direct stores
-                const int64_t yo = out_offset(m);
-                if (a.vec_store && ch + 3 < a.Cout) {
-                    Pack<T, 4>::store(yg + yo + ch, v);
-                } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ch + r < a.Cout) yg[yo + ch + r] = from_f32<T>(v[r]);
+            for (int tm = 0; tm < TM; ++tm) {
+                if (flags[tm] & tapmask) {
+#pragma unroll
+                    for (int ks = 0; ks < KS; ++ks) xf[ks][tm] = bf16x8{};
                 }
             }
-        }
-        if constexpr (STATS) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[r] += __shfl_xor(s1[r], o, 64);
-                    s2[r] += __shfl_xor(s2[r], o, 64);
-                }
-            }
-            if (l15 == 0) {
+                for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    red[(wm * 2 + 0) * BN + chl + r] = s1[r];
-                    red[(wm * 2 + 1) * BN + chl + r] = s2[r];
-                }
-            }
+                    for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
         }
     }
-    }  // consumer
-    __syncthreads();
-    if constexpr (STATS) {
-        if (tid_all < 2 * BN) {
-            const int which = tid_all / BN, chl = tid_all % BN;
-            float sum = 0.f;
-#pragma unroll
-            for (int q = 0; q < WM; ++q) sum += red[(q * 2 + which) * BN + chl];
-            const int ch = n0 + chl;
-            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.Cout + ch] = sum;
-        }
-    }
-    if (a.vec16) {
-        constexpr int CPW = BN * ES / 16;  // 16-byte chunks per output row
-        constexpr int EPC = 16 / ES;       // elements per chunk
-#pragma unroll 4
-        for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
-            const int row = idx / CPW, cc = idx % CPW;
-            const int m = m0 + row, ch = n0 + cc * EPC;
-            if (m < a.M && ch < a.Cout) {
-                const u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
-                *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
-            }
-        }
-    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
+    igemm_epilogue<T, BM, BN, WM, WN, STATS, 256>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -628,7 +773,58 @@ static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats,
     return rc;
 }
 
+// the LDS-resident-input kernel for 3x3 stride-1 problems; returns 1 when the problem is not of that kind
+static int launch_conv3(const IgemmArgs& a0, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
+    static const int env = getenv("YMI_CONV3") ? atoi(getenv("YMI_CONV3")) : 0;  // off: measured 5-50 % SLOWER than the per-tap gather although it moves 40 % fewer bytes (profiles/r02_conv_bench_conv3.txt)
+    if (!env || dtype != YMI_BF16 || a0.ntaps != 9 || a0.s_in != 1 || a0.s_out != 1 || a0.H != a0.Ho || a0.W != a0.Wo || a0.Hy != a0.Ho || a0.Wy != a0.Wo) return 1;
+    if (a0.cpt % 4 != 0 || a0.W < 2 || a0.H < 2) return 1;
+    for (int t = 0; t < 9; ++t) {
+        const int dh = (int)((a0.tap_dh >> (4 * t)) & 15) - 8, dw = (int)((a0.tap_dw >> (4 * t)) & 15) - 8;
+        if (dh < -1 || dh > 1 || dw < -1 || dw > 1) return 1;
+    }
+    const int cpr = (a0.cpt % 8) == 0 ? 8 : 4;
+    const int bn = a0.Cout <= 64 ? 64 : 128;
+    const int R = 128 + 2 * (a0.W + 1);
+    const int a_bytes = (R * cpr + 255) / 256 * 4096;
+    size_t lds = (size_t)a_bytes + (size_t)2 * bn * cpr * 16;
+    const size_t epi = (size_t)128 * (bn * 2 + 16) + (stats ? 4 * 2 * bn * sizeof(float) : 0);
+    if (epi > lds) lds = epi;
+    if (lds > 96 * 1024) return 1;  // wide maps with many channels per row: the image would leave one workgroup per CU
+    IgemmArgs a = a0;
+    a.nmb = (a.M + 127) / 128;
+    a.nnb = (a.Cout + bn - 1) / bn;
+    a.mpx = (a.nmb + 7) / 8;
+    if (host_blocks) *host_blocks = a.nmb;
+    dim3 grid((unsigned)(8 * a.mpx * a.nnb));
+    int prof = -1;
+    if (ymi_prof_enabled()) {
+        const double flop = 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot;
+        const double bytes = (double)a.ktot * a.Cout * 2.0 + (double)a.M * a.Cout * 2.0 * (a.res ? 2.0 : 1.0) + (double)a.M * a.cpt * 16.0;
+        prof = ymi_prof_start(stream, 0, flop, bytes, 2500.0);
+    }
+#define YMI_C3(BN_, CPR_)                                                                                                         \
+    do {                                                                                                                          \
+        if (stats) {                                                                                                              \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<BN_, CPR_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
+            hipLaunchKernelGGL((conv3_kernel<BN_, CPR_, true>), grid, dim3(256), lds, stream, a, R, a_bytes);                      \
+        } else {                                                                                                                  \
+            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<BN_, CPR_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+            hipLaunchKernelGGL((conv3_kernel<BN_, CPR_, false>), grid, dim3(256), lds, stream, a, R, a_bytes);                     \
+        }                                                                                                                         \
+    } while (0)
+    if (bn == 128 && cpr == 8) YMI_C3(128, 8);
+    else if (bn == 128) YMI_C3(128, 4);
+    else if (cpr == 8) YMI_C3(64, 8);
+    else YMI_C3(64, 4);
+#undef YMI_C3
+    ymi_prof_stop(stream, prof);
+    YMI_CHECK_LAUNCH("conv3");
+    return YMI_OK;
+}
+
 int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
+    const int rc = launch_conv3(a, dtype, stats, host_blocks, stream);
+    if (rc != 1) return rc;
     return launch_igemm_n(&a, 1, dtype, stats, host_blocks, stream);
 }
 
@@ -770,7 +966,7 @@ extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad
     }
     static const int fuse_env = getenv("YMI_DGRAD_FUSE") ? atoi(getenv("YMI_DGRAD_FUSE")) : 1;  // 0: one launch per parity class
     // (measured: fusing pays from 64 output channels up; the 32-channel layer 1 is 6 % faster class by class)
-    if (fuse_env && cin >= 64) return nlaunch ? launch_igemm_n(classes, nlaunch, dy->dtype, false, nullptr, (hipStream_t)stream) : YMI_OK;
+    if (fuse_env && cin >= 64 && nlaunch > 1) return launch_igemm_n(classes, nlaunch, dy->dtype, false, nullptr, (hipStream_t)stream);
     for (int i = 0; i < nlaunch; ++i) {
         int rc = ymi_launch_igemm(classes[i], dy->dtype, false, nullptr, (hipStream_t)stream);
         if (rc) return rc;
