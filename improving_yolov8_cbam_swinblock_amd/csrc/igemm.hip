@@ -69,6 +69,21 @@ __device__ __forceinline__ int fast_div(int n, uint32_t mul, uint32_t shr, int d
     return mul ? (int)(__umulhi((uint32_t)n, mul) >> shr) : n;
 }
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+// compile-time knob.  0 (default): a step's pieces are issued back to back right after the barrier.  1: spread between
+// the MFMAs of the step - measured 1.1x (data gradient) to 2x (forward) SLOWER (profiles/r02_conv_bench_interleave.txt):
+// with one step of prefetch the pieces need the whole step to land, and issuing them late exposes that latency.
+#ifndef YMI_PIECE_INTERLEAVE
+#define YMI_PIECE_INTERLEAVE 0
+#endif
+
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     // one K step = CPR 16-byte chunks per row = CPR/4 16x16x32 MFMAs per tile pair.
@@ -116,6 +131,59 @@ template <> struct Mma<bf16_t> {
                 for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+    }
+
+    // The same K step with the NP LDS-DMA pieces of a LATER step spread between its MFMAs: piece(p) is called after MFMA
+    // (2p+1)*NM/(2NP) of the NM in the step.  Issued back to back at the head of the step (next to the 16 fragment reads)
+    // a piece holds its wave for 100-185 cycles, among MFMAs for 25-60 (MI355X_MICROARCH.md, LDS-DMA piece issue cost).
+    template <int TM, int TN, int CPR, int NP, class F>
+    static __device__ __forceinline__ void step_issue(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM], F&& piece) {
+        constexpr int ROWB = CPR * 16;
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int sw = CPR == 4 ? ((-(l15 >> 2)) & 3) : ((l15 >> 1) & 7);
+        constexpr int KS = CPR / 4;
+        constexpr int NM = KS * TN * TM;
+        static_assert(NM >= NP, "at least one MFMA per piece");
+        bf16x8 wf[KS][TN], xf[KS][TM];
+        const uint32_t bbase = (uint32_t)(uintptr_t)(lptr_t)(Bs + (b_row0 + l15) * ROWB);
+        const uint32_t abase = (uint32_t)(uintptr_t)(lptr_t)(As + (a_row0 + l15) * ROWB);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint32_t coff = (uint32_t)(((4 * ks + l4) ^ sw) << 4);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[ks][tn]) : "v"(bbase + coff), "n"(tn * 16 * ROWB));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[ks][tm]) : "v"(abase + coff), "n"(tm * 16 * ROWB));
+        }
+        static_for<0, KS>([&](auto ksc) {
+            constexpr int ks = decltype(ksc)::value;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (ks + 1 < KS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(wf[ks][tn]));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(xf[ks][tm]));
+            static_for<0, TN>([&](auto tnc) {
+                constexpr int tn = decltype(tnc)::value;
+                static_for<0, TM>([&](auto tmc) {
+                    constexpr int tm = decltype(tmc)::value;
+                    constexpr int q = (ks * TN + tn) * TM + tm;
+                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+                    static_for<0, NP>([&](auto pc) {
+                        constexpr int pp = decltype(pc)::value;
+                        if constexpr (q == ((2 * pp + 1) * NM) / (2 * NP)) {
+                            __builtin_amdgcn_sched_barrier(0);
+                            piece(pc);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    });
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
     }
 };
 template <> struct Mma<float> {
@@ -435,6 +503,29 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
         }
     };
 
+    // one LDS-DMA piece of a FAST K step (pieces 0..NA-1: A rows, NA..NA+NB-1: B rows; the last one advances the tap)
+    auto piece_of = [&](int s, auto pc) {
+        constexpr int p = decltype(pc)::value;
+        char* As = smem + s * STAGE;
+        char* Bs = As + BM * ROWB;
+        if constexpr (p < NA) {
+            __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[p], (lptr_t)(As + (p * LT + wave * 64) * 16), 16, 0, 0);
+            a_ptr[p] += a_inc[p];
+        } else {
+            constexpr int j = p - NA;
+            if ((wave * RPW + RPI * j) < BN) {  // wave-uniform
+                __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[j], (lptr_t)(Bs + (j * LT + wave * 64) * 16), 16, 0, 0);
+                b_ptr[j] += b_inc[j];
+            }
+        }
+        if constexpr (p == NA + NB - 1) {
+            if (--left == 0) {  // next tap (scalar branch)
+                left = steps_per_tap;
+                if (++tap_s < a.ntaps) setup_tap(tap_s);
+            }
+        }
+    };
+
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -470,7 +561,16 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
                 wait_vmcnt_barrier<0>();  // pipeline tail: fewer steps in flight than the count assumes
             }
             // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
-            if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
+            if constexpr (YMI_PIECE_INTERLEAVE && FAST && !SPEC && std::is_same<T, bf16_t>::value && (CPR / 4) * TM * TN >= NA + NB) {
+                if (kt + NS - 1 < nkt) {  // ... with the pieces spread between this step's MFMAs
+                    const int sn = (kt + NS - 1) % NS;
+                    const char* As = smem + (kt % NS) * STAGE;
+                    Mma<T>::template step_issue<TM, TN, CPR, NA + NB>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc, [&](auto pc) { piece_of(sn, pc); });
+                    continue;
+                }
+            } else {
+                if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
+            }
         } else {
             asm volatile("s_barrier" ::: "memory");  // the loading waves waited for step kt's pieces before they arrived here
         }
@@ -717,9 +817,11 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
         if constexpr (std::is_same<T, bf16_t>::value) {
             YMI_CHECK_ARG(wide, "igemm: the 256x128 tile needs 128-byte operand rows");
             nthreads = 512;
-            lds = (size_t)2 * (256 + 128) * 128;
+            static const int big_ns = getenv("YMI_IGEMM_BIG_NS") ? atoi(getenv("YMI_IGEMM_BIG_NS")) : 2;  // ring depth of the 256x128 tile (3: 144 KB of LDS, two K steps in flight)
+            lds = (size_t)(big_ns == 3 ? 3 : 2) * (256 + 128) * 128;
             if (epi > lds) lds = epi;
-            YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 2, 8, true, STATS, false, 512>));
+            if (big_ns == 3) YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512>));
+            else YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 2, 8, true, STATS, false, 512>));
         } else {
             ymi_set_error("igemm: the 256x128 tile is bf16 only");
             return YMI_EINVAL;
