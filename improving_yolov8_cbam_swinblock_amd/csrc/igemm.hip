@@ -33,6 +33,42 @@
 
 #include "common.h"
 
+#ifdef YMI_STAMPS
+// diagnostic build only: per-wave s_memtime stamps of one workgroup's K steps 2..9 (phases marked in the loops below), kept
+// in a spare 4 KB of LDS during the loop and copied out at the end.  extern "C" ymi_debug_stamp_buffer sets the target.
+__device__ unsigned long long* g_stamp_buf = nullptr;
+extern "C" int ymi_debug_stamp_buffer(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_stamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define YMI_STAMP_DECL                                                                                     \
+    const bool stamp_on = g_stamp_buf && blockIdx.x == gridDim.x / 2 && lane == 0;                         \
+    unsigned long long* stamp_lds = reinterpret_cast<unsigned long long*>(smem + stamp_off) + wave_all * 64; \
+    int stamp_i = 0;                                                                                        \
+    const unsigned long long stamp_mt0 = stamp_on ? __builtin_amdgcn_s_memtime() : 0ull, stamp_rt0 = stamp_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define YMI_STAMP(kt)                                                                   \
+    do {                                                                                \
+        if (stamp_on && (kt) >= 2 && (kt) < 10 && stamp_i < 64) stamp_lds[stamp_i++] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#define YMI_STAMP_DUMP                                                                  \
+    do {                                                                                \
+        if (stamp_on) {                                                                 \
+            for (int q = 0; q < 64; ++q) g_stamp_buf[wave_all * 64 + q] = q < stamp_i ? stamp_lds[q] : 0ull; \
+            /* clock calibration: shader cycles and 100 MHz ticks over the whole K loop */ \
+            g_stamp_buf[8 * 64 + wave_all * 2 + 0] = __builtin_amdgcn_s_memtime() - stamp_mt0; \
+            g_stamp_buf[8 * 64 + wave_all * 2 + 1] = __builtin_amdgcn_s_memrealtime() - stamp_rt0; \
+        }                                                                               \
+    } while (0)
+#define YMI_STAMP_MARK(i)                                                               \
+    do {                                                                                \
+        if (stamp_on) g_stamp_buf[8 * 64 + 16 + wave_all * 8 + (i)] = __builtin_amdgcn_s_memtime() - stamp_mt0; \
+    } while (0)
+#else
+#define YMI_STAMP_MARK(i) do { } while (0)
+#define YMI_STAMP_DECL
+#define YMI_STAMP(kt) do { } while (0)
+#define YMI_STAMP_DUMP do { } while (0)
+#endif
+
 struct IgemmArgs {
     const void* x;
     const void* w;
@@ -133,6 +169,44 @@ template <> struct Mma<bf16_t> {
         }
     }
 
+    // The two halves of a K step for the ping-pong kernel: fragment reads into registers (memory phase) ...
+    template <int TM, int TN, int CPR>
+    static __device__ __forceinline__ void read_frags(const char* As, const char* Bs, int a_row0, int b_row0, int lane, bf16x8 (&wf)[CPR / 4][TN],
+                                                      bf16x8 (&xf)[CPR / 4][TM]) {
+        constexpr int ROWB = CPR * 16;
+        constexpr int KS = CPR / 4;
+        const int l15 = lane & 15, l4 = lane >> 4;
+        const int sw = CPR == 4 ? ((-(l15 >> 2)) & 3) : ((l15 >> 1) & 7);
+        const uint32_t bbase = (uint32_t)(uintptr_t)(lptr_t)(Bs + (b_row0 + l15) * ROWB);
+        const uint32_t abase = (uint32_t)(uintptr_t)(lptr_t)(As + (a_row0 + l15) * ROWB);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const uint32_t coff = (uint32_t)(((4 * ks + l4) ^ sw) << 4);
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[ks][tn]) : "v"(bbase + coff), "n"(tn * 16 * ROWB));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[ks][tm]) : "v"(abase + coff), "n"(tm * 16 * ROWB));
+        }
+    }
+    // ... and the MFMAs on those registers (compute phase)
+    template <int TM, int TN, int CPR>
+    static __device__ __forceinline__ void mma_frags(bf16x8 (&wf)[CPR / 4][TN], bf16x8 (&xf)[CPR / 4][TM], f32x4 (&acc)[TN][TM]) {
+        constexpr int KS = CPR / 4;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(wf[ks][tn]));
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(xf[ks][tm]));
+#pragma unroll
+            for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+        }
+    }
+
     // The same K step with the NP LDS-DMA pieces of a LATER step spread between its MFMAs: piece(p) is called after MFMA
     // (2p+1)*NM/(2NP) of the NM in the step.  Issued back to back at the head of the step (next to the 16 fragment reads)
     // a piece holds its wave for 100-185 cycles, among MFMAs for 25-60 (MI355X_MICROARCH.md, LDS-DMA piece issue cost).
@@ -209,6 +283,19 @@ template <> struct Mma<float> {
 };
 
 
+// sum of a value over the 16 lanes of its DPP row, result in every lane: xor-1 and xor-2 quad permutes, then the half-row and
+// row mirrors (each lane already holds its quad's / half-row's total, so the mirrored partner supplies the other one)
+template <int CTRL> __device__ __forceinline__ float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);  // row_half_mirror
+    v = dpp_add<0x140>(v);  // row_mirror
+    return v;
+}
+
 // ---- epilogue shared by the GEMM kernels -------------------------------------------------------------------------
 // The tile leaves through LDS: lanes drop their 4-channel groups into a [pixel][channel] image, then the workgroup
 // stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines (per-lane 8-byte stores
@@ -216,7 +303,11 @@ template <> struct Mma<float> {
 // per-block BatchNorm partial sums; otherwise scale / bias / activation / up to two addends.
 template <typename T, int BM, int BN, int WM, int WN, bool STATS, int NT>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], char* smem, int m0, int n0, int mb, int wm,
-                                               int wn, int lane, int tid_all, bool consumer) {
+                                               int wn, int lane, int tid_all, bool consumer
+#ifdef YMI_STAMPS
+                                               , bool stamp_on = false, int wave_all = 0, unsigned long long stamp_mt0 = 0
+#endif
+                                               ) {
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     const int l15 = lane & 15, l4 = lane >> 4;
     T* yg = reinterpret_cast<T*>(a.y);
@@ -238,7 +329,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     };
     auto out_offset = [&](int m) -> int64_t { return out_pixel(m) * a.ldy; };
 
+    // Code size matters here: this block is unrolled TN x TM times around register-indexed accumulators, and every workgroup runs
+    // it once.  With the activation (erff), the scalar residual fall-backs and the unaligned stores inlined per tile it was 11,500
+    // instructions - in-kernel stamps (profiles/r02_igemm_phase_stamps.txt) showed 10-11 k cycles for this phase, 20 % of a
+    // workgroup's life on an 18-step layer and 30-45 % on 1x1 layers (instruction fetch, not arithmetic).  So the per-tile code
+    // only scales, adds the aligned addends and drops the tile into LDS; activation, unaligned addends and unaligned stores
+    // work on the LDS image in run-time loops below.
+    const int act = STATS ? (int)YMI_ACT_NONE : a.act;
+    const bool res1 = !STATS && rg && a.vec_store && (a.Cout & 3) == 0 && act == YMI_ACT_NONE;  // addends joined per tile (f32, before the one rounding)
+    const bool res2nd = !STATS && rg && !res1;                              // ... or after the activation, from the LDS image
     if (consumer) {
+    int64_t rpx[TM];
+    if (res1) {
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+            const int m = m0 + (wm * TM + tm) * 16 + l15;
+            rpx[tm] = m < a.M ? out_pixel(m) : -1;
+        }
+    }
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
         const int chl = (wn * TN + tn) * 16 + 4 * l4;  // channel within the block tile
@@ -256,7 +364,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
             const int row = (wm * TM + tm) * 16 + l15;
-            const int m = m0 + row;
             float v[4];
             if constexpr (STATS) {
 #pragma unroll
@@ -267,47 +374,29 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(acc[tn][tm][r] * sc[r] + bi[r], a.act);
-                if (rg && m < a.M) {
-                    const int64_t px = out_pixel(m);
-                    if (a.vec_store && ch + 3 < a.Cout) {
-                        float rr[4];
-                        Pack<T, 4>::load(rg + px * a.ldres + ch, rr);
+                for (int r = 0; r < 4; ++r) v[r] = acc[tn][tm][r] * sc[r] + bi[r];
+                if (res1 && rpx[tm] >= 0 && ch + 3 < a.Cout) {
+                    float rr[4];
+                    Pack<T, 4>::load(rg + rpx[tm] * a.ldres + ch, rr);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                    if (rg2) {
+                        Pack<T, 4>::load(rg2 + rpx[tm] * a.ldres2 + ch, rr);
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                        if (rg2) {
-                            Pack<T, 4>::load(rg2 + px * a.ldres2 + ch, rr);
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                        }
-                    } else {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r)
-                            if (ch + r < a.Cout) v[r] += to_f32(rg[px * a.ldres + ch + r]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch + r]) : 0.f);
                     }
                 }
             }
-            if (a.vec16) {
-                Pack<T, 4>::store(reinterpret_cast<T*>(Cimg + row * CROW) + chl, v);
-            } else if (m < a.M) {  // unaligned / odd channel counts: direct stores
-                const int64_t yo = out_offset(m);
-                if (a.vec_store && ch + 3 < a.Cout) {
-                    Pack<T, 4>::store(yg + yo + ch, v);
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (ch + r < a.Cout) yg[yo + ch + r] = from_f32<T>(v[r]);
-                }
-            }
+            Pack<T, 4>::store(reinterpret_cast<T*>(Cimg + row * CROW) + chl, v);
         }
         if constexpr (STATS) {
+            // sum over the 16 lanes of a DPP row (= the 16 pixels of the tile) with 4 DPP adds per value; __shfl_xor compiles to
+            // ds_bpermute_b32 - 128 LDS-pipe round trips per wave that queue behind the other workgroup's fragment reads
+            // (stamps: 11 k cycles for this block, profiles/r02_igemm_phase_stamps.txt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s1[r] += __shfl_xor(s1[r], o, 64);
-                    s2[r] += __shfl_xor(s2[r], o, 64);
-                }
+                s1[r] = row16_sum(s1[r]);
+                s2[r] = row16_sum(s2[r]);
             }
             if (l15 == 0) {
 #pragma unroll
@@ -319,7 +408,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         }
     }
     }  // consumer
+    YMI_STAMP_MARK(3);  // accumulators converted and dropped into the LDS image
     __syncthreads();
+    YMI_STAMP_MARK(4);  // past the barrier
     if constexpr (STATS) {
         if (tid_all < 2 * BN) {
             const int which = tid_all / BN, chl = tid_all % BN;
@@ -333,16 +424,63 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     if (a.vec16) {
         constexpr int CPW = BN * ES / 16;  // 16-byte chunks per output row
         constexpr int EPC = 16 / ES;       // elements per chunk
+        const bool post = act != YMI_ACT_NONE || res2nd;  // (workgroup-uniform) something left to do on the stored values
+        if (!post) {
 #pragma unroll 4
-        for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
-            const int row = idx / CPW, cc = idx % CPW;
-            const int m = m0 + row, ch = n0 + cc * EPC;
+            for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
+                const int row = idx / CPW, cc = idx % CPW;
+                const int m = m0 + row, ch = n0 + cc * EPC;
+                if (m < a.M && ch < a.Cout) {
+                    const u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
+                    *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
+                }
+            }
+        } else {  // rare: fused inference convolutions (SiLU, then the shortcut), addends that are only element-aligned
+#pragma unroll 1
+            for (int idx = tid_all; idx < BM * CPW * (EPC / 4); idx += NT) {
+                const int row = idx / (CPW * (EPC / 4)), q = idx % (CPW * (EPC / 4));  // q: group of 4 channels in the row
+                const int m = m0 + row, ch = n0 + q * 4;
+                if (m < a.M && ch < a.Cout) {
+                    float v[4], rr[4];
+                    Pack<T, 4>::load(reinterpret_cast<const T*>(Cimg + row * CROW) + q * 4, v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(v[r], act);
+                    if (res2nd) {
+                        const int64_t px = out_pixel(m);
+                        if (a.vec_store) {
+                            Pack<T, 4>::load(rg + px * a.ldres + ch, rr);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                            if (rg2) {
+                                Pack<T, 4>::load(rg2 + px * a.ldres2 + ch, rr);
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] += to_f32(rg[px * a.ldres + ch + r]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch + r]) : 0.f);
+                        }
+                    }
+                    Pack<T, 4>::store(yg + out_offset(m) + ch, v);  // vec16 output: 4-element groups are aligned
+                }
+            }
+        }
+    } else {
+        // unaligned / odd channel counts (Detect's class maps at small nc, first-layer data gradients): one element per lane and trip
+        for (int idx = tid_all; idx < BM * BN; idx += NT) {
+            const int row = idx / BN, col = idx % BN;
+            const int m = m0 + row, ch = n0 + col;
             if (m < a.M && ch < a.Cout) {
-                const u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
-                *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
+                float v = apply_act_rt(to_f32(reinterpret_cast<const T*>(Cimg + row * CROW)[col]), act);
+                if (res2nd) {
+                    const int64_t px = out_pixel(m);
+                    v += to_f32(rg[px * a.ldres + ch]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch]) : 0.f);
+                }
+                yg[out_offset(m) + ch] = from_f32<T>(v);
             }
         }
     }
+    YMI_STAMP_MARK(5);  // stores issued
 }
 
 // SPEC: wave specialisation.  512-thread workgroup: waves 0-3 multiply (LDS fragment reads + MFMA, the same 2x2 wave grid),
@@ -353,7 +491,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 // of the workgroup; the two roles meet at ONE barrier per K step.
 // NTHR = 512 without SPEC: eight waves that all load and multiply (256x128 tiles in a 4x2 wave grid of 64x64 wave tiles:
 // 0.75x the operand bytes per FLOP of the 128x128 tile at the same registers per wave).
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false, int NTHR = (SPEC ? 512 : 256)>
+// PP: ping-pong.  512-thread workgroup, 256-row tile: waves 0-3 own rows 0-127, waves 4-7 rows 128-255, and the two halves run
+// half a K step apart.  A half's step is a MEMORY phase (fragment reads of step k into registers, its share of the LDS-DMA
+// pieces of step k+2, waits) followed by a COMPUTE phase (32 MFMAs on registers only), every phase ends at a workgroup
+// barrier, so each SIMD always holds one wave in its memory phase beside one in its compute phase (the arrangement
+// MI355X_MICROARCH.md, Two waves per SIMD, describes) instead of two waves in the same phase.  Three LDS stages: the pieces
+// of step k+2 overwrite the stage of step k-1, which both halves finished reading at least one phase earlier.
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false, int NTHR = (SPEC ? 512 : 256), bool PP = false>
 __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -366,6 +510,9 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     static_assert(WM * WN == (SPEC ? 4 : NTHR / 64), "one wave tile per multiplying wave");
     static_assert((BM * CPR) % LT == 0, "every loading wave issues all A loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef YMI_STAMPS
+    constexpr int stamp_off = NS * STAGE;  // the launcher adds 4 KB behind the ring in this build
+#endif
 
     constexpr int NT = NTHR;
     const int tid_all = threadIdx.x, lane = tid_all & 63;
@@ -373,6 +520,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     const bool loader = !SPEC || wave_all >= 4, consumer = !SPEC || wave_all < 4;
     const int tid = SPEC ? (tid_all & 255) : tid_all, wave = SPEC ? (wave_all & 3) : wave_all;  // index inside the role's waves
     const int wm = wave / WN, wn = wave % WN;
+    YMI_STAMP_DECL
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id & 7), each with its own L2.  Every XCD gets a
     // CONTIGUOUS range of M blocks (neighbouring pixel tiles share 3x3 halo rows) and walks the N blocks of one M block
     // back to back, so the A tile an M block gathers is fetched into that XCD's L2 once and reused by all its N blocks
@@ -526,6 +674,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
         }
     };
 
+    YMI_STAMP_MARK(0);  // prologue (address set-up) done
     f32x4 acc[TN][TM];
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -537,7 +686,103 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     constexpr int LPT_AONLY = NA;  // waves beyond the B tile's rows (BN < 64) issue no B loads
     const bool b_wave = (BN >= RPI) || (wave * RPW < BN);
     const int nkt = (a.KC + CPR - 1) / CPR;
-    if constexpr (NS == 1) {
+    if constexpr (PP) {
+        static_assert(NTHR == 512 && NS == 3 && !SPEC && FAST && CPR == 8 && std::is_same<T, bf16_t>::value && WM == 4, "ping-pong form: 512 threads, 3 stages, bf16, 128-byte rows");
+        const int half = wave_all >> 2;  // 0: rows 0..BM/2-1 (starts first), 1: the other rows, half a step behind
+        bf16x8 wf[CPR / 4][TN], xf[CPR / 4][TM];
+        issue(0);
+        if (nkt > 1) issue(1);
+        // step 0 (and only it) has landed when the pieces of step 1 may still be outstanding
+        if (nkt > 1) {
+            if (b_wave) wait_vmcnt_barrier<LPT_FULL>();
+            else wait_vmcnt_barrier<LPT_AONLY>();
+        } else {
+            wait_vmcnt_barrier<0>();
+        }
+        if (half == 1) asm volatile("s_barrier" ::: "memory");  // the second half idles one phase
+        // Phase p (p = 0, 1, ...) is the memory phase of step p/2 for half 0 (p even) and of step (p-1)/2 for half 1 (p odd).
+        // Step k+1 is read in phases 2k+2 (half 0) and 2k+3 (half 1), so ALL its pieces must be in LDS when phase 2k+1 ends:
+        // half 0 waits for its share at the end of its compute phase of step k, half 1 at the end of its memory phase of
+        // step k - each then has only its pieces of step k+2 outstanding.  Those pieces go to the stage of step k-1, last read
+        // in phase 2k-1, and are issued in phases 2k / 2k+1.
+        // The pieces of step k+2 are split between the two phases of step k (stamps, profiles/r02_igemm_phase_stamps.txt: with all
+        // six in the memory phase it lasted ~1000 cycles against ~500 of MFMAs): the A rows go out in the memory phase, the
+        // weight rows between the MFMAs, and the pointer / tap bookkeeping follows the last MFMA, outside the memory phase.
+        constexpr int NMEM = NA;           // pieces issued in the memory phase (pieces are numbered A rows first)
+        constexpr int NPC = NA + NB;       // pieces per wave and step
+        constexpr int NM = (CPR / 4) * TN * TM;
+        auto load_piece = [&](int s, auto pc) {  // piece p of the step whose stage is s, WITHOUT advancing the pointers
+            constexpr int p = decltype(pc)::value;
+            char* Ad = smem + s * STAGE;
+            char* Bd = Ad + BM * ROWB;
+            if constexpr (p < NA) __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[p], (lptr_t)(Ad + (p * LT + wave * 64) * 16), 16, 0, 0);
+            else __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[p - NA], (lptr_t)(Bd + ((p - NA) * LT + wave * 64) * 16), 16, 0, 0);
+        };
+        auto advance = [&]() {  // what issue() does after its loads
+#pragma unroll
+            for (int i = 0; i < NA; ++i) a_ptr[i] += a_inc[i];
+#pragma unroll
+            for (int jj = 0; jj < NB; ++jj) b_ptr[jj] += b_inc[jj];
+            if (--left == 0) {
+                left = steps_per_tap;
+                if (++tap_s < a.ntaps) setup_tap(tap_s);
+            }
+        };
+        static_assert(BN >= RPI * NB, "every wave issues every weight piece");
+        for (int kt = 0; kt < nkt; ++kt) {
+            const bool more = kt + 2 < nkt;
+            const int sn = (kt + 2) % NS;
+            // ---- memory phase of step kt
+            YMI_STAMP(kt);  // 0: phase start
+            const char* As = smem + (kt % NS) * STAGE;
+            Mma<T>::template read_frags<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, wf, xf);
+            if (more) static_for<0, NMEM>([&](auto pc) { load_piece(sn, pc); });
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            YMI_STAMP(kt);  // 1: fragments in registers, A pieces issued
+            if (half == 1) {
+                if (more) wait_vmcnt_barrier<NMEM>();  // everything older than this phase's pieces: all of step kt+1
+                else wait_vmcnt_barrier<0>();
+            } else {
+                asm volatile("s_barrier" ::: "memory");
+            }
+            // ---- compute phase of step kt
+            YMI_STAMP(kt);  // 2: past the barrier that ends the memory phase
+            __builtin_amdgcn_sched_barrier(0);
+            static_for<0, CPR / 4>([&](auto ksc) {
+                constexpr int ks = decltype(ksc)::value;
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(wf[ks][tn]));
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(xf[ks][tm]));
+                static_for<0, TN>([&](auto tnc) {
+                    constexpr int tn = decltype(tnc)::value;
+                    static_for<0, TM>([&](auto tmc) {
+                        constexpr int tm = decltype(tmc)::value;
+                        constexpr int q = (ks * TN + tn) * TM + tm;
+                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+                        static_for<NMEM, NPC>([&](auto pc) {  // weight piece j after MFMA 4 + 6 j
+                            constexpr int pp = decltype(pc)::value;
+                            if constexpr (q == 4 + 6 * (pp - NMEM) && q < NM) {
+                                __builtin_amdgcn_sched_barrier(0);
+                                if (more) load_piece(sn, pc);
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        });
+                    });
+                });
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            if (more) advance();
+            YMI_STAMP(kt);  // 3: MFMAs issued, pointers advanced
+            if (half == 0) {
+                if (more) wait_vmcnt_barrier<NPC>();  // everything older than step kt+2's pieces
+                else wait_vmcnt_barrier<0>();
+            } else {
+                asm volatile("s_barrier" ::: "memory");
+            }
+        }
+        if (half == 0) asm volatile("s_barrier" ::: "memory");  // the first half waits out the second half's last phase
+    } else if constexpr (NS == 1) {
         // single LDS stage: no overlap inside a workgroup, half the LDS, so twice the resident workgroups overlap each other
         for (int kt = 0; kt < nkt; ++kt) {
             issue(0);
@@ -552,6 +797,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             if (s < nkt) issue(s);
     }
     for (int kt = 0; kt < nkt; ++kt) {
+        YMI_STAMP(kt);  // 0: step start
         if (loader) {
             // K step kt has landed when at most the loads of the NS-2 younger steps are outstanding
             if (kt + NS - 2 < nkt) {
@@ -560,6 +806,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             } else {
                 wait_vmcnt_barrier<0>();  // pipeline tail: fewer steps in flight than the count assumes
             }
+            YMI_STAMP(kt);  // 1: past the wait + barrier
             // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
             if constexpr (YMI_PIECE_INTERLEAVE && FAST && !SPEC && std::is_same<T, bf16_t>::value && (CPR / 4) * TM * TN >= NA + NB) {
                 if (kt + NS - 1 < nkt) {  // ... with the pieces spread between this step's MFMAs
@@ -574,19 +821,29 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
         } else {
             asm volatile("s_barrier" ::: "memory");  // the loading waves waited for step kt's pieces before they arrived here
         }
+        YMI_STAMP(kt);  // 2: pieces issued
         if (consumer) {
             const char* As = smem + (kt % NS) * STAGE;
             Mma<T>::template step<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
         }
+        YMI_STAMP(kt);  // 3: fragments read, MFMAs issued
     }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
+    YMI_STAMP_DUMP;
+    YMI_STAMP_MARK(1);  // K loop done
 
     // ---- epilogue -----------------------------------------------------------------------------
     // The tile leaves through LDS: lanes drop their 4-channel groups into a [pixel][channel] image, then the
     // workgroup stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines
     // (per-lane 8-byte stores to 16 different rows cost 2-3x the time of the same bytes stored this way).
+#ifdef YMI_STAMPS
+    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer, stamp_on, wave_all, stamp_mt0);
+#else
     igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer);
+#endif
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    YMI_STAMP_MARK(2);  // epilogue done, stores retired
 }
 
 // ---- 3x3 stride-1 convolution (forward and data gradient) with the input rows of the tile resident in LDS ---------------
@@ -727,6 +984,7 @@ __global__ __launch_bounds__(256) void conv3_kernel(IgemmArgs a, int R, int a_by
 // ------------------------------------------------------------------------------------------------
 struct TileChoice {
     int bm, bn;
+    bool pp = false;  // ping-pong form of the 256x128 tile
 };
 
 // Largest tile that still yields ~1.5 workgroups per CU (measured on the 40x40 / 20x20 layers of the model: 400 tiles of
@@ -756,6 +1014,11 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats,
     static const int big_env = getenv("YMI_IGEMM_BIG") ? atoi(getenv("YMI_IGEMM_BIG")) : 0;  // 0: off (measured 5-30 % SLOWER wherever it applies: profiles/r02_conv_bench_big.txt)
     if (big_env > 0 && stats_bf16_hint && cout >= 128 && ktot % 64 == 0 && blocks(256, 128) >= big_env) {
         t.bm = 256; t.bn = 128;
+    }
+    // ping-pong form of the same tile (the two 128-row halves half a K step apart), where it leaves >= `pp_env` workgroups
+    static const int pp_env = getenv("YMI_IGEMM_PP") ? atoi(getenv("YMI_IGEMM_PP")) : 0;
+    if (pp_env > 0 && stats_bf16_hint && cout >= 128 && ktot % 64 == 0 && blocks(256, 128) >= pp_env) {
+        t.bm = 256; t.bn = 128; t.pp = true;
     }
     static const char* tile_env = getenv("YMI_IGEMM_TILE");  // "bm,bn": force a tile (tuning knob)
     if (tile_env) {
@@ -796,8 +1059,14 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     if (epi > lds) lds = epi;
     unsigned nthreads = 256;
     static const int ns_env = getenv("YMI_IGEMM_NS") ? atoi(getenv("YMI_IGEMM_NS")) : 2;  // LDS ring depth of the 128-byte-row kernels (tuning knob)
+#ifdef YMI_STAMPS
+#define YMI_STAMP_LDS 4096
+#else
+#define YMI_STAMP_LDS 0
+#endif
 #define YMI_LAUNCH1(KERNEL)                                                                                          \
     do {                                                                                                             \
+        lds += YMI_STAMP_LDS;                                                                                        \
         if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL(KERNEL, grid, dim3(nthreads), lds, stream, P);                                             \
     } while (0)
@@ -820,7 +1089,10 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
             static const int big_ns = getenv("YMI_IGEMM_BIG_NS") ? atoi(getenv("YMI_IGEMM_BIG_NS")) : 2;  // ring depth of the 256x128 tile (3: 144 KB of LDS, two K steps in flight)
             lds = (size_t)(big_ns == 3 ? 3 : 2) * (256 + 128) * 128;
             if (epi > lds) lds = epi;
-            if (big_ns == 3) YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512>));
+            if (t.pp) {
+                lds = (size_t)3 * (256 + 128) * 128;
+                YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512, true>));
+            } else if (big_ns == 3) YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512>));
             else YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 2, 8, true, STATS, false, 512>));
         } else {
             ymi_set_error("igemm: the 256x128 tile is bf16 only");

@@ -49,6 +49,35 @@ SHAPES = [
 ]
 
 
+def stamp_dump(L, fn, title):
+    """one more launch with the stamp buffer armed; prints, per wave, cycles between the 4 marks of K steps 2..9."""
+    buf = torch.zeros(8 * 64 + 16 + 64, dtype=torch.int64, device="cuda:0")
+    L.ymi_debug_stamp_buffer.argtypes = [ctypes.c_void_p]
+    L.ymi_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    fn()
+    torch.cuda.synchronize()
+    L.ymi_debug_stamp_buffer(ctypes.c_void_p(0))
+    host = buf.cpu()
+    st = host[: 8 * 64].view(8, 64)
+    cal = host[8 * 64: 8 * 64 + 16].view(8, 2)
+    marks = host[8 * 64 + 16:].view(8, 8)
+    for w in range(8):
+        if int(marks[w, 2]) > 0:
+            print(f"wave {w}: cycles from kernel entry: prologue done {int(marks[w, 0])}, K loop done {int(marks[w, 1])}, tile in LDS {int(marks[w, 3])}, past barrier {int(marks[w, 4])}, stores issued {int(marks[w, 5])}, stores retired {int(marks[w, 2])}")
+    for w in range(8):
+        if int(cal[w, 1]) > 0:
+            print(f"wave {w}: K loop {int(cal[w, 0])} shader cycles in {int(cal[w, 1]) * 10} ns -> in-kernel clock {int(cal[w, 0]) / (int(cal[w, 1]) * 10.0):.2f} GHz")
+    print(f"--- stamps: {title}  (s_memtime ticks; marks 0->1->2->3->next 0)")
+    t0 = min(int(v) for v in st[:, 0] if int(v) > 0) if (st[:, 0] > 0).any() else 0
+    for w in range(8):
+        row = [int(v) for v in st[w] if int(v) > 0]
+        if not row:
+            continue
+        d = [row[i + 1] - row[i] for i in range(len(row) - 1)]
+        steps = [d[i:i + 4] for i in range(0, len(d) - 3, 4)]
+        print(f"wave {w}: first mark at +{row[0] - t0}; per step [0->1, 1->2, 2->3, 3->next]:", " ".join(str(x) for x in steps[:8]))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--dtype", default="bf16")
@@ -56,6 +85,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
+    ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DYMI_STAMPS) only: print the s_memtime stamps of one workgroup's K steps")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     dev = torch.device("cuda:0")
@@ -110,6 +140,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
+            if args.stamps and nm in ("fwd", "dgrad"):
+                stamp_dump(L, fn, f"{name} {nm} ({us:.1f} us)")
             tot[nm] += us * count
             line += f" {us:8.1f} {gf / us * 1e-3 * 1e3 / 1e3 * 1e3:6.0f} |" if False else f" {us:8.1f} {gf / (us * 1e-6) / 1e3:6.0f} |"
         print(line, flush=True)

@@ -12,6 +12,7 @@ LDS-DMA loads); WRITE_SIZE is exact for the 16-byte stores of the staged epilogu
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
@@ -38,11 +39,23 @@ def collect(root, counter):
     return per
 
 
+def kernel_rev():
+    """hash of the kernel sources the passes were taken on (same rule as bench.py: it reports the traffic only for these)."""
+    h = hashlib.sha1()
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "improving_yolov8_cbam_swinblock_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(fh.read())
+    return h.hexdigest()[:12]
+
+
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
     fetch = collect(fetch_dir, "FETCH_SIZE")
     write = collect(write_dir, "WRITE_SIZE")
-    res = {"recipe": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged per launch over every launch of the family in the profiled run",
+    res = {"kernel_rev": kernel_rev(),
+           "recipe": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged per launch over every launch of the family in the profiled run",
            "families": {}}
     for fam in FAMILIES:
         fk, fn = fetch[fam]
