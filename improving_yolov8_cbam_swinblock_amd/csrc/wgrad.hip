@@ -19,6 +19,20 @@ bool ymi_prof_enabled();
 int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, double peak_tflops);
 void ymi_prof_stop(hipStream_t stream, int idx);
 
+#ifdef YMI_STAMPS
+// diagnostic build only (see igemm.hip): cycles from kernel entry at three marks of one workgroup + the in-kernel clock
+__device__ unsigned long long* g_wstamp_buf = nullptr;
+extern "C" int ymi_debug_stamp_buffer_wgrad(void* p) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_wstamp_buf), &p, sizeof(p)) == hipSuccess ? 0 : -1;
+}
+#define WG_MARK(i)                                                                                              \
+    do {                                                                                                        \
+        if (wstamp_on) g_wstamp_buf[8 * 64 + 16 + wave * 8 + (i)] = __builtin_amdgcn_s_memtime() - wstamp_mt0; \
+    } while (0)
+#else
+#define WG_MARK(i) do { } while (0)
+#endif
+
 struct WgradArgs {
     const void* x;
     const void* dy;
@@ -86,7 +100,7 @@ template <> struct WFrag<bf16_t> {
 #pragma unroll
             for (int a = 0; a < TR; ++a)
 #pragma unroll
-                for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);  // operands swapped: see the epilogue
         }
     }
 };
@@ -104,7 +118,7 @@ template <> struct WFrag<float> {
 #pragma unroll
             for (int a = 0; a < TR; ++a)
 #pragma unroll
-                for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
+                for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[b], af[a], acc[a][b], 0, 0, 0);
         }
     }
 };
@@ -125,6 +139,10 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 1, wc = wave & 1;
+#ifdef YMI_STAMPS
+    const bool wstamp_on = g_wstamp_buf && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0;
+    const unsigned long long wstamp_mt0 = wstamp_on ? __builtin_amdgcn_s_memtime() : 0ull, wstamp_rt0 = wstamp_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#endif
     // XCD-aware order (xcd_map): workgroup ids are dealt round-robin to the 8 XCDs; all tiles of one pixel split read the
     // same dY / X rows (the nine taps are the same pixels, shifted), so a split's tiles are given to ONE XCD, back to
     // back, and its rows are fetched into that L2 once.  Splits are dealt z = 8*i + xcd (balanced within one split).
@@ -195,6 +213,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
 #pragma unroll
         for (int c = 0; c < TC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    WG_MARK(0);  // prologue done
     // NS-stage LDS ring, one raw barrier per K step, loads of NS-2 younger steps stay in flight (see igemm.hip)
     const int nk = (m_end - m_begin + WG_BK - 1) / WG_BK;
     constexpr int LPT = NY + NX;
@@ -209,19 +228,33 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         WFrag<T>::template step<BM, TR, TC>(Ys, Ys + YBYTES, wr * (BM / 2), wc * 64, lane, acc);
     }
 
+    WG_MARK(1);  // K loop done
+#ifdef YMI_STAMPS
+    if (wstamp_on) g_wstamp_buf[8 * 64 + 16 + wave * 8 + 6] = nk;
+#endif
     float* slab = a.slab + (int64_t)bz * a.CoutP * a.NG;
+    // The MFMA operands are swapped (A = the X fragment, B = the dY fragment), so a lane's four accumulator values are four
+    // CONSECUTIVE (tap, ci) columns of one output channel: one 16-byte store instead of four 4-byte stores to four rows
+    // (stores are issue-bound on this chip: 8 / 16 instructions per lane instead of 32 / 64).  NG is a multiple of 4.
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
-    for (int r = 0; r < TR; ++r)
+    for (int r = 0; r < TR; ++r) {
+        const int co = co0 + wr * (BM / 2) + r * 16 + l15;
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
-            const int col = j0 + wc * 64 + c * 16 + l15;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int co = co0 + wr * (BM / 2) + r * 16 + 4 * l4 + e;
-                if (co < a.CoutP && col < a.NG) slab[(int64_t)co * a.NG + col] = acc[r][c][e];
-            }
+            const int col = j0 + wc * 64 + c * 16 + 4 * l4;
+            if (co < a.CoutP && col < a.NG) *reinterpret_cast<f32x4*>(slab + (int64_t)co * a.NG + col) = acc[r][c];
         }
+    }
+    WG_MARK(5);  // stores issued
+#ifdef YMI_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    WG_MARK(2);  // stores retired
+    if (wstamp_on) {
+        g_wstamp_buf[8 * 64 + wave * 2 + 0] = __builtin_amdgcn_s_memtime() - wstamp_mt0;
+        g_wstamp_buf[8 * 64 + wave * 2 + 1] = __builtin_amdgcn_s_memrealtime() - wstamp_rt0;
+    }
+#endif
 }
 
 // Slab reduction, one launch, deterministic: a 1024-thread workgroup owns 32 consecutive outputs (one 128-byte

@@ -49,20 +49,24 @@ SHAPES = [
 ]
 
 
-def stamp_dump(L, fn, title):
+def stamp_dump(L, fn, title, wgrad=False):
     """one more launch with the stamp buffer armed; prints, per wave, cycles between the 4 marks of K steps 2..9."""
     buf = torch.zeros(8 * 64 + 16 + 64, dtype=torch.int64, device="cuda:0")
-    L.ymi_debug_stamp_buffer.argtypes = [ctypes.c_void_p]
-    L.ymi_debug_stamp_buffer(ctypes.c_void_p(buf.data_ptr()))
+    setter = L.ymi_debug_stamp_buffer_wgrad if wgrad else L.ymi_debug_stamp_buffer
+    setter.argtypes = [ctypes.c_void_p]
+    setter(ctypes.c_void_p(buf.data_ptr()))
     fn()
     torch.cuda.synchronize()
-    L.ymi_debug_stamp_buffer(ctypes.c_void_p(0))
+    setter(ctypes.c_void_p(0))
     host = buf.cpu()
     st = host[: 8 * 64].view(8, 64)
     cal = host[8 * 64: 8 * 64 + 16].view(8, 2)
     marks = host[8 * 64 + 16:].view(8, 8)
     for w in range(8):
         if int(marks[w, 2]) > 0:
+            if wgrad:
+                print(f"wave {w}: {int(marks[w, 6])} K steps; cycles from kernel entry: prologue done {int(marks[w, 0])}, K loop done {int(marks[w, 1])}, stores issued {int(marks[w, 5])}, stores retired {int(marks[w, 2])}")
+                continue
             print(f"wave {w}: cycles from kernel entry: prologue done {int(marks[w, 0])}, K loop done {int(marks[w, 1])}, tile in LDS {int(marks[w, 3])}, past barrier {int(marks[w, 4])}, stores issued {int(marks[w, 5])}, stores retired {int(marks[w, 2])}")
     for w in range(8):
         if int(cal[w, 1]) > 0:
@@ -140,8 +144,8 @@ def main():
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / args.iters
-            if args.stamps and nm in ("fwd", "dgrad"):
-                stamp_dump(L, fn, f"{name} {nm} ({us:.1f} us)")
+            if args.stamps:
+                stamp_dump(L, fn, f"{name} {nm} ({us:.1f} us)", nm == "wgrad")
             tot[nm] += us * count
             line += f" {us:8.1f} {gf / us * 1e-3 * 1e3 / 1e3 * 1e3:6.0f} |" if False else f" {us:8.1f} {gf / (us * 1e-6) / 1e3:6.0f} |"
         print(line, flush=True)
