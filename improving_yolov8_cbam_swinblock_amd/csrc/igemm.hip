@@ -75,6 +75,10 @@ struct IgemmArgs {
     void* y;
     const void* res;
     const void* res2;  // second addend of the epilogue (gradient sums of tensors with several consumers)
+    void* y2;          // optional second output: act2(value stored to y)  (Swin MLP: pre-activation and GELU of it from one GEMM)
+    const void* mul;   // optional multiplier: y = value * act'(mul) with mul_act's derivative (GELU backward inside fc2's data gradient)
+    int64_t ldy2, ldmul;
+    int act2, mul_act;
     const float* scale;
     const float* bias;
     float* partials;
@@ -424,7 +428,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     if (a.vec16) {
         constexpr int CPW = BN * ES / 16;  // 16-byte chunks per output row
         constexpr int EPC = 16 / ES;       // elements per chunk
-        const bool post = act != YMI_ACT_NONE || res2nd;  // (workgroup-uniform) something left to do on the stored values
+        const T* mulp = STATS ? nullptr : reinterpret_cast<const T*>(a.mul);
+        const bool post = act != YMI_ACT_NONE || res2nd || mulp;  // (workgroup-uniform) something left to do on the stored values
         if (!post) {
 #pragma unroll 4
             for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
@@ -435,33 +440,69 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
                     *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
                 }
             }
-        } else {  // rare: fused inference convolutions (SiLU, then the shortcut), addends that are only element-aligned
+        } else {  // fused inference convolutions (SiLU, then the shortcut), element-aligned addends, activation-gradient multiplier
 #pragma unroll 1
-            for (int idx = tid_all; idx < BM * CPW * (EPC / 4); idx += NT) {
-                const int row = idx / (CPW * (EPC / 4)), q = idx % (CPW * (EPC / 4));  // q: group of 4 channels in the row
-                const int m = m0 + row, ch = n0 + q * 4;
-                if (m < a.M && ch < a.Cout) {
-                    float v[4], rr[4];
-                    Pack<T, 4>::load(reinterpret_cast<const T*>(Cimg + row * CROW) + q * 4, v);
+            for (int idx = tid_all; idx < BM * CPW; idx += NT) {
+                const int row = idx / CPW, cc = idx % CPW;
+                const int m = m0 + row, ch0 = n0 + cc * EPC;
+                if (m < a.M && ch0 < a.Cout) {
+                    u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
+                    T* vp = reinterpret_cast<T*>(&val);
+                    const int64_t px = (res2nd || mulp) ? out_pixel(m) : 0;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(v[r], act);
-                    if (res2nd) {
-                        const int64_t px = out_pixel(m);
-                        if (a.vec_store) {
-                            Pack<T, 4>::load(rg + px * a.ldres + ch, rr);
+                    for (int h = 0; h < EPC / 4; ++h) {
+                        const int ch = ch0 + 4 * h;
+                        float v[4], rr[4];
+                        Pack<T, 4>::load(vp + 4 * h, v);
+                        if (act != YMI_ACT_NONE) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                            if (rg2) {
-                                Pack<T, 4>::load(rg2 + px * a.ldres2 + ch, rr);
+                            for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(v[r], act);
+                        }
+                        if (res2nd) {
+                            if (a.vec_store) {
+                                Pack<T, 4>::load(rg + px * a.ldres + ch, rr);
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] += rr[r];
-                            }
-                        } else {
+                                if (rg2) {
+                                    Pack<T, 4>::load(rg2 + px * a.ldres2 + ch, rr);
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] += to_f32(rg[px * a.ldres + ch + r]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch + r]) : 0.f);
+                                    for (int r = 0; r < 4; ++r) v[r] += rr[r];
+                                }
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] += to_f32(rg[px * a.ldres + ch + r]) + (rg2 ? to_f32(rg2[px * a.ldres2 + ch + r]) : 0.f);
+                            }
                         }
+                        if (mulp) {  // (host: 4-element-aligned)
+                            Pack<T, 4>::load(mulp + px * a.ldmul + ch, rr);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] *= act_grad_rt(rr[r], a.mul_act);
+                        }
+                        Pack<T, 4>::store(vp + 4 * h, v);
                     }
-                    Pack<T, 4>::store(yg + out_offset(m) + ch, v);  // vec16 output: 4-element groups are aligned
+                    *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch0) = val;
+                }
+            }
+        }
+        if (!STATS && a.y2) {  // second output: the activation of what was just stored (read back from the LDS image, so both outputs
+                               // see the same rounded value - the arithmetic of a separate activation kernel reading the first output)
+            T* y2g = reinterpret_cast<T*>(a.y2);
+#pragma unroll 1
+            for (int idx = tid_all; idx < BM * CPW; idx += NT) {
+                const int row = idx / CPW, cc = idx % CPW;
+                const int m = m0 + row, ch0 = n0 + cc * EPC;
+                if (m < a.M && ch0 < a.Cout) {
+                    u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
+                    T* vp = reinterpret_cast<T*>(&val);
+#pragma unroll
+                    for (int h = 0; h < EPC / 4; ++h) {
+                        float v[4];
+                        Pack<T, 4>::load(vp + 4 * h, v);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = apply_act_rt(v[r], a.act2);
+                        Pack<T, 4>::store(vp + 4 * h, v);
+                    }
+                    *reinterpret_cast<u32x4*>(y2g + out_pixel(m) * a.ldy2 + ch0) = val;
                 }
             }
         }
@@ -1234,10 +1275,16 @@ extern "C" int64_t ymi_conv2d_stat_blocks(int64_t m_rows, int64_t cout) {
     return (m_rows + 63) / 64 + 64;  // smallest BM any tile choice uses, + the 64 staging rows ymi_bn_finalize may append
 }
 
-extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
-                              const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
-                              float* stat_partials, int64_t* host_stat_blocks, void* stream) {
+static int conv_fwd_impl(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                         const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
+                         const ymi_tensor* y2, int32_t act2, float* stat_partials, int64_t* host_stat_blocks, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(y) && w_packed, "conv2d_fwd: bad tensor");
+    if (y2) {
+        YMI_CHECK_ARG(ymi_tensor_ok(y2) && ymi_same_shape(y2, y) && y2->dtype == y->dtype && !stat_partials, "conv2d_fwd: second output");
+        const int epc = (int)(16 / ymi_esize(y->dtype));
+        YMI_CHECK_ARG(y2->ld % epc == 0 && ((uintptr_t)y2->data & 15) == 0 && y->ld % epc == 0 && ((uintptr_t)y->data & 15) == 0 && cout % epc == 0,
+                      "conv2d_fwd: a second output needs 16-byte-aligned rows");
+    }
     YMI_CHECK_ARG(x->dtype == y->dtype, "conv2d_fwd: dtype mismatch");
     const int ch = x->dtype == YMI_BF16 ? 8 : 4;
     YMI_CHECK_ARG(x->c % ch == 0 && x->ld % ch == 0, "conv2d_fwd: input channels (%lld, ld %lld) must be a multiple of %d",
@@ -1264,6 +1311,7 @@ extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t
         for (int j = 0; j < kw; ++j) { dh[i * kw + j] = i - (int)pad; dw[i * kw + j] = j - (int)pad; }
     pack_taps(dh, dw, a.ntaps, &a.tap_dh, &a.tap_dw);
     a.act = act;
+    a.y2 = y2 ? y2->data : nullptr; a.ldy2 = y2 ? y2->ld : 0; a.act2 = act2;
     const int g = 4;
     a.vec_store = (y->ld % g == 0) && (((uintptr_t)y->data) % (g * ymi_esize(y->dtype)) == 0) &&
                   (!residual || (residual->ld % g == 0 && ((uintptr_t)residual->data) % (g * ymi_esize(y->dtype)) == 0));
@@ -1272,6 +1320,12 @@ extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t
     int rc = ymi_launch_igemm(a, x->dtype, stat_partials != nullptr, &blocks, (hipStream_t)stream);
     if (host_stat_blocks) *host_stat_blocks = blocks;
     return rc;
+}
+
+extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                              const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
+                              float* stat_partials, int64_t* host_stat_blocks, void* stream) {
+    return conv_fwd_impl(x, w_packed, cout, kh, kw, stride, scale, bias, act, residual, y, nullptr, YMI_ACT_NONE, stat_partials, host_stat_blocks, stream);
 }
 
 // dx = sum over taps of dy (x) w : stride 1 -> one launch; stride 2 -> one launch per output parity class.
@@ -1285,9 +1339,23 @@ extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_pac
     return ymi_conv2d_bwd_data_add(dy, w_dgrad_packed, cin, kh, kw, stride, nullptr, nullptr, dx, stream);
 }
 
+static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
+                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream);
+
 extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw,
                                        int64_t stride, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream) {
+    return dgrad_impl(dy, w_dgrad_packed, cin, kh, kw, stride, add1, add2, nullptr, YMI_ACT_NONE, dx, stream);
+}
+
+static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
+                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && w_dgrad_packed, "conv2d_bwd_data: bad tensor");
+    if (mul) {
+        const int epc = (int)(16 / ymi_esize(dx->dtype));
+        YMI_CHECK_ARG(ymi_tensor_ok(mul) && ymi_same_shape(mul, dx) && mul->dtype == dx->dtype && mul->ld % 4 == 0 &&
+                          ((uintptr_t)mul->data) % (4 * ymi_esize(dx->dtype)) == 0 && dx->ld % epc == 0 && ((uintptr_t)dx->data & 15) == 0 && cin % epc == 0,
+                      "conv2d_bwd_data: the multiplier needs the output's shape and 16-byte-aligned output rows");
+    }
     if (add1 || add2) {
         YMI_CHECK_ARG(add1 && ymi_tensor_ok(add1) && ymi_same_shape(add1, dx) && add1->dtype == dx->dtype, "conv2d_bwd_data_add: first addend");
         YMI_CHECK_ARG(!add2 || (ymi_tensor_ok(add2) && ymi_same_shape(add2, dx) && add2->dtype == dx->dtype), "conv2d_bwd_data_add: second addend");
@@ -1327,6 +1395,7 @@ extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad
             a.Cout = (int)cin; a.cpt = (int)(dy->c / ch); a.ntaps = nt; a.KC = nt * a.cpt; a.ktot = (int64_t)a.KC * ch;
             pack_taps(dh, dw, nt, &a.tap_dh, &a.tap_dw);
             a.act = YMI_ACT_NONE;
+            a.mul = mul ? mul->data : nullptr; a.ldmul = mul ? mul->ld : 0; a.mul_act = mul_act;
             a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0) &&
                           (!add1 || (add1->ld % 4 == 0 && ((uintptr_t)add1->data) % (4 * es) == 0)) &&
                           (!add2 || (add2->ld % 4 == 0 && ((uintptr_t)add2->data) % (4 * es) == 0));
@@ -1346,4 +1415,28 @@ extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad
         if (rc) return rc;
     }
     return YMI_OK;
+}
+
+// ---- SwinBlock MLP (swin_block.py:33,53: Linear(C, 4C) -> GELU -> Linear(4C, C), + the skip) ------------------------------------
+// forward: two GEMM launches.  fc1's epilogue stores the pre-activation (saved for backward) AND its exact-erf GELU, so the
+// [T, 4C] matrix is written twice and never read back by an activation kernel; fc2 adds the bias and the skip in its epilogue.
+extern "C" int ymi_swin_mlp_fwd(const ymi_tensor* u, const void* w1_packed, const float* b1, int64_t hidden, const void* w2_packed, const float* b2,
+                                const ymi_tensor* residual, const ymi_tensor* pre, const ymi_tensor* post, const ymi_tensor* out, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(u) && ymi_tensor_ok(pre) && ymi_tensor_ok(post) && ymi_tensor_ok(out) && w1_packed && w2_packed, "swin_mlp_fwd: bad tensor");
+    YMI_CHECK_ARG(pre->c == hidden && post->c == hidden && out->c == u->c, "swin_mlp_fwd: channels");
+    int rc = conv_fwd_impl(u, w1_packed, hidden, 1, 1, 1, nullptr, b1, YMI_ACT_NONE, nullptr, pre, post, YMI_ACT_GELU, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return conv_fwd_impl(post, w2_packed, out->c, 1, 1, 1, nullptr, b2, YMI_ACT_NONE, residual, out, nullptr, YMI_ACT_NONE, nullptr, nullptr, stream);
+}
+
+// backward, data path: d_pre = (d_out . W2) * gelu'(pre) in fc2's data-gradient epilogue (no [T, 4C] gradient of the activation
+// output is ever stored), then d_u = d_pre . W1 (+ up to two addends: the gradient sums of the tensor LayerNorm-2 produced).
+// Weight and bias gradients are ordinary ymi_conv2d_bwd_weight calls on (post, d_out) and (u, d_pre).
+extern "C" int ymi_swin_mlp_bwd_data(const ymi_tensor* dout, const void* w2_dgrad_packed, const ymi_tensor* pre, const ymi_tensor* dpre,
+                                     const void* w1_dgrad_packed, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* du, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(dout) && ymi_tensor_ok(pre) && ymi_tensor_ok(dpre) && w2_dgrad_packed, "swin_mlp_bwd_data: bad tensor");
+    int rc = dgrad_impl(dout, w2_dgrad_packed, pre->c, 1, 1, 1, nullptr, nullptr, pre, YMI_ACT_GELU, dpre, stream);
+    if (rc || !du) return rc;
+    YMI_CHECK_ARG(ymi_tensor_ok(du) && w1_dgrad_packed, "swin_mlp_bwd_data: bad tensor");
+    return dgrad_impl(dpre, w1_dgrad_packed, du->c, 1, 1, 1, add1, add2, nullptr, YMI_ACT_NONE, du, stream);
 }

@@ -53,6 +53,5 @@ class SwinBlock(nn.Module):
         if join:
             ops.mark_join(t2, 2)
         u = ops.layernorm(t2, self.norm2, 0)
-        hdn = ops.gelu(ops.linear(u, self.mlp[0].weight, self.mlp[0].bias))
-        t3 = ops.linear(hdn, self.mlp[2].weight, self.mlp[2].bias, residual=t2)
+        t3 = ops.swin_mlp(u, self.mlp[0], self.mlp[2], residual=t2)  # fc1 -> GELU -> fc2 -> + t2, GELU inside the GEMM epilogues
         return ops.window_reverse(t3, n, h, w, ws, out)

@@ -697,6 +697,71 @@ def linear(x, weight, bias=None, residual=None):
     return _ConvAffineAct.apply(x, weight, None, bias, 1, ACT_NONE, residual, weight.shape[0], join_of(x), join_of(residual) if residual is not None else None)
 
 
+class _SwinMlp(torch.autograd.Function):
+    """out = fc2(gelu(fc1(u))) + residual on token matrices (swin_block.py:33,53) through ymi_swin_mlp_fwd / _bwd_data: GELU rides
+    in fc1's epilogue (second output) and its derivative in fc2's data-gradient epilogue, so the [T, 4C] activation and its
+    gradient are never passed through stand-alone activation kernels."""
+
+    @staticmethod
+    def forward(ctx, u, w1, b1, w2, b2, residual, join, res_join):
+        dtype = u.dtype
+        t, c = u.shape
+        hidden = w1.shape[0]
+        dev = u.device
+        pre = torch.empty((t, hidden), dtype=dtype, device=dev)
+        post = torch.empty((t, hidden), dtype=dtype, device=dev)
+        out = torch.empty((t, w2.shape[0]), dtype=dtype, device=dev)
+        w1p = pack_conv_fwd(w1, c, dtype)
+        w2p = pack_conv_fwd(w2, hidden, dtype)
+        check(
+            L().ymi_swin_mlp_fwd(_byref(as_ymi(u)), ptr(w1p), ptr(b1), hidden, ptr(w2p), ptr(b2), _byref(as_ymi(residual)) if residual is not None else None,
+                                 _byref(as_ymi(pre)), _byref(as_ymi(post)), _byref(as_ymi(out)), stream_ptr()),
+            "swin_mlp_fwd",
+        )
+        ctx.save_for_backward(u, w1, w2, pre, post)
+        ctx.cfg = (b1 is not None, b2 is not None, residual is not None)
+        ctx.joins = (join, res_join)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, w1, w2, pre, post = ctx.saved_tensors
+        has_b1, has_b2, has_res = ctx.cfg
+        dtype = u.dtype
+        dout = grad_nhwc(dout, dtype)
+        join, res_join = ctx.joins
+        dres = _join_plain(res_join, dout) if (has_res and ctx.needs_input_grad[5]) else None
+        t, c = u.shape
+        hidden = w1.shape[0]
+        dpre = torch.empty_like(pre)
+        need_du = ctx.needs_input_grad[0]
+        adds = (join.arrive() if join is not None else []) if need_du else []
+        fa = _prep_adds(adds, dtype, False)
+        du = torch.empty((t, c), dtype=dtype, device=u.device) if need_du else None
+        w2d = pack_conv_dgrad(w2, w2.shape[0], 1, dtype)
+        w1d = pack_conv_dgrad(w1, hidden, 1, dtype) if need_du else None
+        check(
+            L().ymi_swin_mlp_bwd_data(_byref(as_ymi(dout)), ptr(w2d), _byref(as_ymi(pre)), _byref(as_ymi(dpre)), ptr(w1d) if need_du else None,
+                                      _byref(as_ymi(fa[0])) if len(fa) > 0 else None, _byref(as_ymi(fa[1])) if len(fa) > 1 else None,
+                                      _byref(as_ymi(du)) if need_du else None, stream_ptr()),
+            "swin_mlp_bwd_data",
+        )
+        if need_du:
+            if len(fa) > 2:
+                _accumulate(du, fa[2:])
+            if adds is None:
+                join.deposit(du)
+                du = None
+        dw2, db2 = _wgrad_maybe_async(post, dout, w2.shape[0], hidden, 1, 1, has_b2)
+        dw1, db1 = _wgrad_maybe_async(u, dpre, hidden, c, 1, 1, has_b1)
+        return du, dw1.view(w1.shape), db1, dw2.view(w2.shape), db2, dres, None, None
+
+
+def swin_mlp(u, fc1, fc2, residual=None):
+    """fc2(gelu(fc1(u))) + residual for the two nn.Linear of SwinBlock.mlp (exact-erf GELU)."""
+    return _SwinMlp.apply(u, fc1.weight, fc1.bias, fc2.weight, fc2.bias, residual, join_of(u), join_of(residual) if residual is not None else None)
+
+
 class _Act(torch.autograd.Function):
     """elementwise activation on a token matrix (exact-erf GELU of swin_block.py:33)."""
 

@@ -305,6 +305,16 @@ int ymi_opt_grad_norm(const ymi_opt_entry* table, const int32_t* chunk_map, int3
 int ymi_opt_update(const ymi_opt_entry* table, const int32_t* chunk_map, int32_t first_tensor, int32_t n_tensors, int64_t n_chunks,
                    const float* const* host_grads, const float* hyper, const void* state, void* stream);
 
+/* SwinBlock MLP: Linear(C,4C) -> exact GELU -> Linear(4C,C) (+ skip).  Reference: ultralytics/nn/modules/swin_block.py:33 (definition)
+ * and :53 (`x = x + self.mlp(self.norm2(x))`).  Token matrices are ymi_tensors with n = h = 1, w = tokens.
+ * fwd: pre = u W1^T + b1 and post = gelu(pre) are both written by fc1's epilogue; out = post W2^T + b2 (+ residual).
+ * bwd_data: dpre = (dout W2) * gelu'(pre) from fc2's data-gradient epilogue; du = dpre W1 (+ add1 + add2); du may be NULL.
+ * Weights are the ymi_pack_conv_weight_fwd / _dgrad images of the two nn.Linear weights viewed as 1x1 convolutions. */
+int ymi_swin_mlp_fwd(const ymi_tensor* u, const void* w1_packed, const float* b1, int64_t hidden, const void* w2_packed, const float* b2,
+                     const ymi_tensor* residual, const ymi_tensor* pre, const ymi_tensor* post, const ymi_tensor* out, void* stream);
+int ymi_swin_mlp_bwd_data(const ymi_tensor* dout, const void* w2_dgrad_packed, const ymi_tensor* pre, const ymi_tensor* dpre,
+                          const void* w1_dgrad_packed, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* du, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
