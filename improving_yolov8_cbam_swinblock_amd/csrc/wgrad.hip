@@ -86,17 +86,19 @@ template <> struct WFrag<bf16_t> {
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
-    template <int BM, int TR, int TC>
+    template <int BM, int TR, int TC, int BNW = WG_BN>
     static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 32; ++ks) {  // pixel rows 32*ks .. 32*ks+31 (the swizzles use row bits 0..3 only)
             const char* Yk = Ys + ks * 32 * BM * 2;
-            const char* Xk = Xs + ks * 32 * WG_BN * 2;
+            const char* Xk = Xs + ks * 32 * BNW * 2;
             bf16x8 af[TR], bfr[TC];
 #pragma unroll
             for (int t = 0; t < TR; ++t) af[t] = load<(BM == 128)>(Yk, BM * 2, r0 + t * 16, lane);  // 256-byte dY rows use the X swizzle
+            // (512-byte X rows of the 256-column tile: the XOR only touches the low five bits of the 8-byte unit index, i.e. it
+            // permutes units inside each 256-byte bank row exactly as for 256-byte rows)
 #pragma unroll
-            for (int t = 0; t < TC; ++t) bfr[t] = load<true>(Xk, WG_BN * 2, c0 + t * 16, lane);
+            for (int t = 0; t < TC; ++t) bfr[t] = load<true>(Xk, BNW * 2, c0 + t * 16, lane);
 #pragma unroll
             for (int a = 0; a < TR; ++a)
 #pragma unroll
@@ -105,8 +107,9 @@ template <> struct WFrag<bf16_t> {
     }
 };
 template <> struct WFrag<float> {
-    template <int BM, int TR, int TC>
+    template <int BM, int TR, int TC, int BNW = WG_BN>
     static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
+        static_assert(BNW == WG_BN, "f32 parity mode uses the 128-column tile");
         const int kq = lane >> 4, i = lane & 15;
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 4; ++ks) {
@@ -125,13 +128,16 @@ template <> struct WFrag<float> {
 
 // BM = output channels per workgroup tile: 64, or 128 for layers with >= 128 output channels (16 instead of 8 MFMAs per
 // wave and K step against the same address arithmetic: the K loop is instruction-issue-bound, not MFMA-bound)
-template <typename T, int NS, int BM>
-__global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
+// BNW = (tap, ci) columns per workgroup tile: 128, or 256 with BM = 128 (experiment: a 128x256 tile moves 24 KB per K step for
+// twice the MFMAs of the 128x128 tile's 16 KB; 64x128 wave tiles, 128 accumulator registers, two workgroups per CU.  Slower, see
+// wgrad_bn).
+template <typename T, int NS, int BM, int BNW = WG_BN>
+__global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
-    constexpr int YCW = BM * ES / 16, XCW = WG_BN * ES / 16;        // 16-byte chunks per tile row
+    constexpr int YCW = BM * ES / 16, XCW = BNW * ES / 16;            // 16-byte chunks per tile row
     constexpr int NY = WG_BK * YCW / 256, NX = WG_BK * XCW / 256;     // chunks per thread per K step
-    constexpr int YBYTES = WG_BK * BM * ES, XBYTES = WG_BK * WG_BN * ES;
+    constexpr int YBYTES = WG_BK * BM * ES, XBYTES = WG_BK * BNW * ES;
     constexpr int STAGE = YBYTES + XBYTES;
     static_assert(NY >= 1 && NX >= 1, "tile too small");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -157,7 +163,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     } else {
         bx = blockIdx.x; by = blockIdx.y; bz = blockIdx.z;
     }
-    const int j0 = bx * WG_BN, co0 = by * BM;
+    const int j0 = bx * BNW, co0 = by * BM;
     const int m_begin = bz * a.pix_per_split;
     const int m_end = min(a.Mpix, m_begin + a.pix_per_split);
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
@@ -170,7 +176,11 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     const int ycc = SWZ ? ((tid % YCW) ^ ((BM == 128 ? wg_swz_x(tid / YCW) : wg_swz_y(tid / YCW)) << 1)) : (tid % YCW);
     const bool y_cok = co0 + ycc * CH < a.CoutP;
     // X loader: column chunk fixed per thread -> fixed tap / input-channel offset
-    const int xcc = SWZ ? ((tid % XCW) ^ (wg_swz_x(tid / XCW) << 1)) : (tid % XCW);
+    // 256-column tile: a block-wide load instruction covers 8 rows, so piece i would start at row 8 i and flip row bit 3 - which the
+    // swizzle uses.  Its pieces go to rows  2 (wave & 1) + 8 (wave >> 1) + 4 (i & 1) + 16 (i >> 1) + (lane >> 5)  instead: row
+    // bits 0, 1 and 3 come from the thread, bits 2 and 4 from the piece, and the thread's source column chunk stays fixed.
+    const int xrow0 = BNW == 256 ? 2 * (wave & 1) + 8 * (wave >> 1) + (lane >> 5) : tid / XCW;
+    const int xcc = SWZ ? ((tid % XCW) ^ (wg_swz_x(xrow0) << 1)) : (tid % XCW);
     const int j = j0 + xcc * CH;
     const bool x_cok = j < a.NG;
     const int tap = x_cok ? j / a.Cin : 0;
@@ -192,7 +202,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         for (int i = 0; i < NX; ++i) {
             // pixel -> (n, ho, wo) by two multiply-highs and 32-bit offsets (the host guarantees pixels * ld < 2^31): the
             // address arithmetic of a K step must stay well below its 8 MFMAs' issue time
-            const int row = tid / XCW + i * (256 / XCW);
+            const int row = BNW == 256 ? xrow0 + 4 * (i & 1) + 16 * (i >> 1) : tid / XCW + i * (256 / XCW);
             const int m = mk + row;
             const int t = wg_fast_div(m, a.wo_mul, a.wo_shr);
             const int wo = m - t * a.Wo;
@@ -202,11 +212,16 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
             const bool ok = x_cok && m < m_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
             const uint32_t off = (uint32_t)(((n * a.H + hi) * a.W + wi) * ldx32 + ci);
             const T* src = ok ? xg + off : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            if constexpr (BNW == 256) {
+                const int rb = 2 * (wave & 1) + 8 * (wave >> 1) + 4 * (i & 1) + 16 * (i >> 1);  // the wave's two rows rb, rb + 1 are 1 KB of LDS
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + rb * (BNW * ES)), 16, 0, 0);
+            } else {
+                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
         }
     };
 
-    constexpr int TR = BM / 32, TC = 4;  // per wave: BM/2 rows x 64 cols
+    constexpr int TR = BM / 32, TC = BNW / 32;  // per wave: BM/2 rows x BNW/2 cols
     f32x4 acc[TR][TC];
 #pragma unroll
     for (int r = 0; r < TR; ++r)
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         else wait_vmcnt_barrier<0>();
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, m_begin + (kt + NS - 1) * WG_BK);
         const char* Ys = smem + (kt % NS) * STAGE;
-        WFrag<T>::template step<BM, TR, TC>(Ys, Ys + YBYTES, wr * (BM / 2), wc * 64, lane, acc);
+        WFrag<T>::template step<BM, TR, TC, BNW>(Ys, Ys + YBYTES, wr * (BM / 2), wc * (BNW / 2), lane, acc);
     }
 
     WG_MARK(1);  // K loop done
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         const int co = co0 + wr * (BM / 2) + r * 16 + l15;
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
-            const int col = j0 + wc * 64 + c * 16 + 4 * l4;
+            const int col = j0 + wc * (BNW / 2) + c * 16 + 4 * l4;
             if (co < a.CoutP && col < a.NG) *reinterpret_cast<f32x4*>(slab + (int64_t)co * a.NG + col) = acc[r][c];
         }
     }
@@ -389,11 +404,19 @@ static int wgrad_bm(int64_t coutp, bool bf16) {
     if (!bf16 || env != 128) return 64;
     return (coutp >= 128 && coutp % 128 == 0) || coutp >= 256 ? 128 : 64;
 }
-static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm = WG_BM) {
-    const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + bm - 1) / bm);
+// column-tile choice.  YMI_WGRAD_BN=256 selects the 128x256 tile wherever the (tap, ci) axis has at least 256 columns: measured
+// 1.1-1.66x SLOWER than 128x128 on every such layer (profiles/r02_conv_bench_wgrad256.txt) although it moves 0.75x the bytes
+// per FLOP - two resident workgroups instead of three, 204 registers; kept as a knob, off by default.
+static int wgrad_bn(int bm, int64_t ng, bool bf16) {
+    static const int env = getenv("YMI_WGRAD_BN") ? atoi(getenv("YMI_WGRAD_BN")) : 128;
+    return (bf16 && env == 256 && bm == 128 && ng >= 256) ? 256 : WG_BN;
+}
+static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm = WG_BM, int bn = WG_BN) {
+    const int64_t tiles = ((ng + bn - 1) / bn) * ((coutp + bm - 1) / bm);
     static const int target64 = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;  // workgroups to aim for (tuning knobs)
     static const int target128 = getenv("YMI_WGRAD_BLOCKS128") ? atoi(getenv("YMI_WGRAD_BLOCKS128")) : 640;
-    const int target = bm == 128 ? target128 : target64;
+    static const int target256 = getenv("YMI_WGRAD_BLOCKS256") ? atoi(getenv("YMI_WGRAD_BLOCKS256")) : 512;  // two resident workgroups per CU
+    const int target = bn == 256 ? target256 : bm == 128 ? target128 : target64;
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t smax = (mpix + 255) / 256;
     if (s > smax) s = smax;
@@ -417,6 +440,8 @@ extern "C" size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, 
     WgradPlan p = wgrad_plan(m_rows, coutp, kh * kw * cinp, 64);
     const WgradPlan p128 = wgrad_plan(m_rows, coutp, kh * kw * cinp, 128);  // the 128-row tile splits the pixel axis further
     if (p128.slab_bytes > p.slab_bytes) p = p128;
+    const WgradPlan p256 = wgrad_plan(m_rows, coutp, kh * kw * cinp, 128, 256);
+    if (p256.slab_bytes > p.slab_bytes) p = p256;
     return p.slab_bytes + (size_t)(2048 * 2 + 1) * coutp * sizeof(float) + 256;
 }
 
@@ -482,7 +507,8 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     const int64_t mpix = ymi_pixels(dy);
     const int64_t ng = kh * kw * x->c;
     const int bm = wgrad_bm(dy->c, x->dtype == YMI_BF16);
-    WgradPlan p = wgrad_plan(mpix, dy->c, ng, bm);
+    const int bn = wgrad_bn(bm, ng, x->dtype == YMI_BF16);
+    WgradPlan p = wgrad_plan(mpix, dy->c, ng, bm, bn);
     size_t need = p.slab_bytes + (dbias ? (size_t)(2048 * 2 + 1) * dy->c * sizeof(float) : 0);
     if (workspace_bytes < need) {
         ymi_set_error("conv2d_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
@@ -496,7 +522,7 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     a.CoutP = (int)dy->c; a.Cin = (int)x->c; a.NG = (int)ng; a.pix_per_split = p.pix_per_split;
     wg_find_divisor(a.Wo, &a.wo_mul, &a.wo_shr);
     wg_find_divisor(a.Ho, &a.ho_mul, &a.ho_shr);
-    a.nx = (int)((ng + WG_BN - 1) / WG_BN); a.ny = (int)((dy->c + bm - 1) / bm); a.splits = p.splits;
+    a.nx = (int)((ng + bn - 1) / bn); a.ny = (int)((dy->c + bm - 1) / bm); a.splits = p.splits;
     static const int xcd_env = getenv("YMI_WGRAD_XCD") ? atoi(getenv("YMI_WGRAD_XCD")) : 1;  // tuning knob
     a.xcd_map = (xcd_env && p.splits >= 8) ? 1 : 0;
     dim3 grid((unsigned)a.nx, (unsigned)a.ny, (unsigned)p.splits);
@@ -511,7 +537,9 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     if (x->dtype == YMI_BF16) {
         static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
         const size_t lds = (size_t)ns * (size_t)(WG_BK * (bm + WG_BN) * 2);
-        if (bm == 128) {
+        if (bn == 256) {
+            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128, 256>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + 256) * 2), s, a);
+        } else if (bm == 128) {
             hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2), s, a);
         } else {
             if (ns > 2) {
