@@ -235,12 +235,22 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s)
         if (s < nk) issue(s, m_begin + s * WG_BK);
+#ifdef YMI_STAMPS
+    int wstamp_i = 0;
+#define WG_STEP_STAMP() do { if (wstamp_on && kt >= 2 && kt < 10 && wstamp_i < 64) g_wstamp_buf[wave * 64 + wstamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define WG_STEP_STAMP() do { } while (0)
+#endif
     for (int kt = 0; kt < nk; ++kt) {
+        WG_STEP_STAMP();  // 0: step start
         if (kt + NS - 2 < nk) wait_vmcnt_barrier<LPT * (NS - 2)>();
         else wait_vmcnt_barrier<0>();
+        WG_STEP_STAMP();  // 1: past wait + barrier
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, m_begin + (kt + NS - 1) * WG_BK);
+        WG_STEP_STAMP();  // 2: pieces issued
         const char* Ys = smem + (kt % NS) * STAGE;
         WFrag<T>::template step<BM, TR, TC, BNW>(Ys, Ys + YBYTES, wr * (BM / 2), wc * (BNW / 2), lane, acc);
+        WG_STEP_STAMP();  // 3: fragments read, MFMAs issued
     }
 
     WG_MARK(1);  // K loop done
