@@ -339,6 +339,12 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     // workgroup's life on an 18-step layer and 30-45 % on 1x1 layers (instruction fetch, not arithmetic).  So the per-tile code
     // only scales, adds the aligned addends and drops the tile into LDS; activation, unaligned addends and unaligned stores
     // work on the LDS image in run-time loops below.
+#ifndef YMI_EPI_PRIO
+#define YMI_EPI_PRIO 2
+#endif
+    // the co-resident workgroup is in its K loop: its MFMAs hold the SIMD's vector issue half of the time and, being older, win
+    // the arbitration - raise this wave's priority for its ~500 VALU instructions so that LDS and the wave slots are freed sooner
+    if (YMI_EPI_PRIO) __builtin_amdgcn_s_setprio(YMI_EPI_PRIO);
     const int act = STATS ? (int)YMI_ACT_NONE : a.act;
     const bool res1 = !STATS && rg && a.vec_store && (a.Cout & 3) == 0 && act == YMI_ACT_NONE;  // addends joined per tile (f32, before the one rounding)
     const bool res2nd = !STATS && rg && !res1;                              // ... or after the activation, from the LDS image

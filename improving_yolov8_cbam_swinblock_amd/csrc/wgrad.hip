@@ -33,6 +33,11 @@ extern "C" int ymi_debug_stamp_buffer_wgrad(void* p) {
 #define WG_MARK(i) do { } while (0)
 #endif
 
+#ifdef YMI_STAMPS
+#define WG_STAMP_LDS 2048
+#else
+#define WG_STAMP_LDS 0
+#endif
 struct WgradArgs {
     const void* x;
     const void* dy;
@@ -187,36 +192,75 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
     const int ci = x_cok ? j - tap * a.Cin : 0;
     const int dh = tap / a.KW - a.pad, dw = tap % a.KW - a.pad;
     const int ldx32 = (int)a.ldx, ldy32 = (int)a.ldy;
+    // Address state of this thread's rows, advanced by WG_BK pixels per K step with adds and compares only (the pixel ->
+    // (n, ho, wo) decomposition by two multiply-highs and five multiplies per piece and step cost ~160 cycles per piece: the
+    // issue phase was half of a K step, stamps in profiles/r02_igemm_phase_stamps.txt section 6).  issue() is called for
+    // consecutive steps m_begin, m_begin + WG_BK, ...: it uses the state and then moves it one step on.
+    //   X row: ws = wo * stride, hs = ho * stride (input coordinates of the tap-(0,0) pixel), xo = element offset of that pixel
+    //          + this thread's tap shift and channel; a step adds (q, r) = divmod(WG_BK, Wo) rows / columns, then wraps.
+    //   Y row: element offset m * ldy + channel.
+    const int s_ = a.stride;
+    const int q_ = WG_BK / a.Wo, r_ = WG_BK - q_ * a.Wo;                   // scalar
+    const uint32_t d_step = (uint32_t)((q_ * s_ * a.W + r_ * s_) * ldx32);   // offset change of (ho += q, wo += r)
+    const uint32_t d_wwrap = (uint32_t)((s_ * a.W - a.Wo * s_) * ldx32);     // ... of (wo -= Wo, ho += 1)
+    const uint32_t d_hwrap = (uint32_t)((a.H * a.W - a.Ho * s_ * a.W) * ldx32);  // ... of (ho -= Ho, n += 1)
+    const int ws_lim = a.Wo * s_, hs_lim = a.Ho * s_;
+    int x_ws[NX], x_hs[NX], x_row[NX];
+    uint32_t x_off[NX];
+#pragma unroll
+    for (int i = 0; i < NX; ++i) {
+        const int row = BNW == 256 ? xrow0 + 4 * (i & 1) + 16 * (i >> 1) : tid / XCW + i * (256 / XCW);
+        const int m = m_begin + row;
+        const int t = wg_fast_div(m, a.wo_mul, a.wo_shr);
+        const int wo = m - t * a.Wo;
+        const int n = wg_fast_div(t, a.ho_mul, a.ho_shr);
+        const int ho = t - n * a.Ho;
+        x_row[i] = row;
+        x_ws[i] = wo * s_;
+        x_hs[i] = ho * s_;
+        x_off[i] = (uint32_t)(((n * a.H + ho * s_ + dh) * a.W + wo * s_ + dw) * ldx32 + ci);
+    }
+    int y_row[NY];
+    uint32_t y_off[NY];
+#pragma unroll
+    for (int i = 0; i < NY; ++i) {
+        y_row[i] = tid / YCW + i * (256 / YCW);
+        y_off[i] = (uint32_t)((m_begin + y_row[i]) * ldy32 + co0 + ycc * CH);
+    }
+    const uint32_t y_step = (uint32_t)(WG_BK * ldy32);
     auto issue = [&](int s, int mk) {
         char* Ys = smem + s * STAGE;
         char* Xs = Ys + YBYTES;
+        const int left = m_end - mk;  // scalar: rows below it are inside this split
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
-            const int row = tid / YCW + i * (256 / YCW);
-            const int m = mk + row;
-            const bool ok = y_cok && m < m_end;
-            const T* src = ok ? yg + (uint32_t)(m * ldy32 + co0 + ycc * CH) : zero;
+            const bool ok = y_cok && y_row[i] < left;
+            const T* src = ok ? yg + y_off[i] : zero;
             __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            y_off[i] += y_step;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
-            // pixel -> (n, ho, wo) by two multiply-highs and 32-bit offsets (the host guarantees pixels * ld < 2^31): the
-            // address arithmetic of a K step must stay well below its 8 MFMAs' issue time
-            const int row = BNW == 256 ? xrow0 + 4 * (i & 1) + 16 * (i >> 1) : tid / XCW + i * (256 / XCW);
-            const int m = mk + row;
-            const int t = wg_fast_div(m, a.wo_mul, a.wo_shr);
-            const int wo = m - t * a.Wo;
-            const int n = wg_fast_div(t, a.ho_mul, a.ho_shr);
-            const int ho = t - n * a.Ho;
-            const int hi = ho * a.stride + dh, wi = wo * a.stride + dw;
-            const bool ok = x_cok && m < m_end && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const uint32_t off = (uint32_t)(((n * a.H + hi) * a.W + wi) * ldx32 + ci);
-            const T* src = ok ? xg + off : zero;
+            const bool ok = x_cok && x_row[i] < left && (unsigned)(x_hs[i] + dh) < (unsigned)a.H && (unsigned)(x_ws[i] + dw) < (unsigned)a.W;
+            const T* src = ok ? xg + x_off[i] : zero;
             if constexpr (BNW == 256) {
                 const int rb = 2 * (wave & 1) + 8 * (wave >> 1) + 4 * (i & 1) + 16 * (i >> 1);  // the wave's two rows rb, rb + 1 are 1 KB of LDS
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + rb * (BNW * ES)), 16, 0, 0);
             } else {
                 __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            }
+            // one K step on
+            x_ws[i] += r_ * s_;
+            x_hs[i] += q_ * s_;
+            x_off[i] += d_step;
+            if (x_ws[i] >= ws_lim) {
+                x_ws[i] -= ws_lim;
+                x_hs[i] += s_;
+                x_off[i] += d_wwrap;
+            }
+            while (x_hs[i] >= hs_lim) {  // at most once unless the map has fewer rows than a K step covers
+                x_hs[i] -= hs_lim;
+                x_off[i] += d_hwrap;
             }
         }
     };
@@ -237,7 +281,9 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
         if (s < nk) issue(s, m_begin + s * WG_BK);
 #ifdef YMI_STAMPS
     int wstamp_i = 0;
-#define WG_STEP_STAMP() do { if (wstamp_on && kt >= 2 && kt < 10 && wstamp_i < 64) g_wstamp_buf[wave * 64 + wstamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+    // stamps go to a spare 2 KB of LDS behind the ring (a global store per stamp would sit in vmcnt and distort the counted waits)
+    unsigned long long* wstamp_lds = reinterpret_cast<unsigned long long*>(smem + NS * STAGE) + wave * 64;
+#define WG_STEP_STAMP() do { if (wstamp_on && kt >= 2 && kt < 10 && wstamp_i < 64) wstamp_lds[wstamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define WG_STEP_STAMP() do { } while (0)
 #endif
@@ -253,6 +299,9 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
         WG_STEP_STAMP();  // 3: fragments read, MFMAs issued
     }
 
+#ifdef YMI_STAMPS
+    if (wstamp_on) for (int q = 0; q < 64; ++q) g_wstamp_buf[wave * 64 + q] = q < wstamp_i ? wstamp_lds[q] : 0ull;
+#endif
     WG_MARK(1);  // K loop done
 #ifdef YMI_STAMPS
     if (wstamp_on) g_wstamp_buf[8 * 64 + 16 + wave * 8 + 6] = nk;
@@ -548,9 +597,9 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
         static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
         const size_t lds = (size_t)ns * (size_t)(WG_BK * (bm + WG_BN) * 2);
         if (bn == 256) {
-            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128, 256>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + 256) * 2), s, a);
+            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128, 256>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + 256) * 2) + WG_STAMP_LDS, s, a);
         } else if (bm == 128) {
-            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2), s, a);
+            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
         } else {
             if (ns > 2) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -558,7 +607,7 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
             }
             if (ns == 4) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 4, 64>), grid, dim3(256), lds, s, a);
             else if (ns == 3) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3, 64>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 64>), grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 64>), grid, dim3(256), lds + WG_STAMP_LDS, s, a);
         }
     } else {
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
