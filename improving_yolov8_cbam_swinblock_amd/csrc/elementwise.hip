@@ -491,9 +491,11 @@ static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const fl
     const int groups = (int)raw->c / 4;
     const int64_t P = ymi_pixels(raw);
     const int rows = 256 / groups;
-    // every thread reloads its group's scale/shift: give it ~8 pixels when the tensor allows, but keep >= 256 blocks
+    // every thread reloads its group's scale/shift: give it ~8 pixels when the tensor allows.  Small maps (<= 13 MB here) are pure
+    // latency: with 256 blocks a thread walked 3-6 pixels one dependent round trip after the other (10 us for 1.6 MB); give them
+    // up to one resident round of blocks, i.e. 1-2 pixels per thread
     int64_t gb = (P + (int64_t)rows * ew_ppt() - 1) / ((int64_t)rows * ew_ppt());
-    if (gb < 256) gb = (P + rows - 1) / rows < 256 ? (P + rows - 1) / rows : 256;
+    if (gb < 1024) gb = (P + rows - 1) / rows < 1024 ? (P + rows - 1) / rows : 1024;
     if (gb > ew_cap()) gb = ew_cap();  // default 2048: one resident round of 256-thread blocks on 256 CUs
     dim3 g((unsigned)gb), b(256);
     if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);

@@ -172,9 +172,16 @@ static int pow2_ge(int v) {
     return p;
 }
 
-// returns number of stage-1 blocks; partials must hold blocks*2*C floats
-static int reduce_blocks(int64_t P) {
-    int64_t b = (P + 63) / 64;  // >= 64 pixels per block
+// returns number of stage-1 blocks; partials must hold blocks*2*C floats.  A block's 256 threads cover 256 / (C/4) pixel rows at a
+// time and walk their pixels four per trip; on the small maps that walk is a chain of dependent HBM round trips (a 13 MB tensor
+// with 200 blocks of 64 pixels took 20 us at C = 512: 8 trips per thread), so a block gets one trip's worth of pixels
+// (>= 16) until the 1024-block cap - the large maps are unchanged.
+static int reduce_blocks(int64_t P, int C) {
+    const int tg = pow2_ge(C / 4) > 256 ? 256 : pow2_ge(C / 4);
+    int64_t ppb = (int64_t)(256 / tg) * 4;
+    if (ppb < 16) ppb = 16;
+    if (ppb > 64) ppb = 64;
+    int64_t b = (P + ppb - 1) / ppb;
     if (b > 1024) b = 1024;
     if (b < 1) b = 1;
     return (int)b;
@@ -188,7 +195,7 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
     YMI_CHECK_ARG(C % 4 == 0 && a->ld % 4 == 0 && (!b || (b->ld % 4 == 0)), "%s: channels must be a multiple of 4", what);
     const int TG = pow2_ge(C / 4) > 256 ? 256 : pow2_ge(C / 4);
     const int crows = (C + 1023) / 1024;
-    const int blocks = reduce_blocks(P);
+    const int blocks = reduce_blocks(P, C);
     const size_t lds = (size_t)256 * 8 * sizeof(float);
     RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
 #define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, part)
@@ -215,7 +222,7 @@ int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, flo
 
 extern "C" int ymi_colsum(const ymi_tensor* x, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(x) && out && workspace, "colsum: args");
-    const size_t need = (size_t)reduce_blocks(ymi_pixels(x)) * 2 * x->c * sizeof(float);
+    const size_t need = (size_t)reduce_blocks(ymi_pixels(x), (int)x->c) * 2 * x->c * sizeof(float);
     if (workspace_bytes < need) {
         ymi_set_error("colsum: workspace %zu < %zu", workspace_bytes, need);
         return YMI_EWORKSPACE;
@@ -229,7 +236,7 @@ extern "C" int ymi_colsum(const ymi_tensor* x, float* out, void* workspace, size
 // LayerNorm parameter gradients (used by swin.hip): dgamma = sum_rows dy*xhat, dbeta = sum_rows dy
 int ymi_ln_param_grads(const ymi_tensor* dy, const ymi_tensor* x, const float* mean, const float* rstd, float* dgamma, float* dbeta,
                        void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    const size_t need = (size_t)reduce_blocks(ymi_pixels(dy)) * 2 * dy->c * sizeof(float);
+    const size_t need = (size_t)reduce_blocks(ymi_pixels(dy), (int)dy->c) * 2 * dy->c * sizeof(float);
     if (workspace_bytes < need) {
         ymi_set_error("layernorm_bwd: workspace %zu < %zu", workspace_bytes, need);
         return YMI_EWORKSPACE;
@@ -320,7 +327,7 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     YMI_CHECK_ARG(draw->ld % 4 == 0, "bn_act_bwd: draw ld");
     const int64_t P = ymi_pixels(dout);
     const int C = (int)dout->c;
-    const int rblocks = reduce_blocks(P);
+    const int rblocks = reduce_blocks(P, C);
     const size_t need = ((size_t)rblocks * 2 * C + 5 * (size_t)C) * sizeof(float);
     if (workspace_bytes < need) {
         ymi_set_error("bn_act_bwd: workspace %zu < %zu", workspace_bytes, need);
@@ -349,7 +356,7 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
         // every thread reloads its group's coefficients: give it at least ~8 pixels when the tensor allows
         const int rows = 256 / groups;
         gb = (P + (int64_t)rows * ew_ppt() - 1) / ((int64_t)rows * ew_ppt());
-        if (gb < 256) gb = (P + rows - 1) / rows < 256 ? (P + rows - 1) / rows : 256;
+        if (gb < 1024) gb = (P + rows - 1) / rows < 1024 ? (P + rows - 1) / rows : 1024;  // small maps: latency, not bandwidth (see launch_ssa_fixed)
     } else {
         gb = (total + 255) / 256;
     }
