@@ -355,6 +355,134 @@ static int launch_pool_bwd(const ymi_tensor* x, int k, const ymi_tensor* gout, c
     return YMI_OK;
 }
 
+// ---- the three stages in ONE launch, for maps that fit LDS whole (the SPPF maps of the model: 20x20) ----------------------------
+// A workgroup owns one image and one 16-byte channel chunk: it stages y0, y1, y2 and the running gradient once and runs
+//   g := dy3;  g := dy2 + route(g | y2);  g := dy1 + route(g | y1);  dy0 += route(g | y0)
+// between LDS images, the running gradient kept in f32 (the per-stage kernel rounds it to the tensor dtype between stages).
+// Same arg-max rule and the same separable row / column search as maxpool_bwd_kernel.  Three launches of ~47 us become one.
+struct PoolBwd3Args {
+    PV y[3];    // y0, y1, y2
+    PV dy[4];   // dy0 (in/out), dy1, dy2, dy3 (in)
+    int N, H, W, C, k;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void sppf_bwd_fused_kernel(PoolBwd3Args a) {
+    constexpr int CN = Chunk<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int HW = a.H * a.W, r = a.k / 2, k = a.k;
+    const int c0 = blockIdx.x * CN, n = blockIdx.y;
+    float* G0 = reinterpret_cast<float*>(smem);                       // [HW][CN] running gradient (ping)
+    float* G1 = G0 + (size_t)HW * CN;                                 // (pong)
+    char* X = reinterpret_cast<char*>(G1 + (size_t)HW * CN);          // [HW][16 B] values of the current stage
+    char* RM = X + (size_t)HW * 16;                                   // [HW][16 B] row maxima
+    unsigned char* RC = reinterpret_cast<unsigned char*>(RM + (size_t)HW * 16);  // [HW][CN] column code of the row maximum
+    unsigned char* IDX = RC + (size_t)HW * CN;                        // [HW][CN] arg-max code of the window centred here
+    const int64_t img = (int64_t)n * HW;
+    // g := dy3
+    {
+        const T* gp = reinterpret_cast<const T*>(a.dy[3].p);
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float v[CN];
+            Chunk<T>::load(gp + (img + i) * a.dy[3].ld + c0, v);
+#pragma unroll
+            for (int e = 0; e < CN; ++e) G0[(size_t)i * CN + e] = v[e];
+        }
+    }
+    float* gcur = G0;
+    float* gnext = G1;
+    for (int st = 2; st >= 0; --st) {
+        const T* xp = reinterpret_cast<const T*>(a.y[st].p);
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float v[CN];
+            Chunk<T>::load(xp + (img + i) * a.y[st].ld + c0, v);
+            Chunk<T>::store(X + (size_t)i * 16, v);
+        }
+        __syncthreads();
+        // row pass: maximum over the k columns around every position, and its column code
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int h = i / a.W, w = i - h * a.W;
+            float best[CN];
+            int code[CN];
+#pragma unroll
+            for (int e = 0; e < CN; ++e) { best[e] = NEG_INF; code[e] = -1; }
+            for (int dx = 0; dx < k; ++dx) {
+                const int ww = w + dx - r;
+                if (ww < 0 || ww >= a.W) continue;
+                float v[CN];
+                Chunk<T>::load(X + (size_t)(h * a.W + ww) * 16, v);
+#pragma unroll
+                for (int e = 0; e < CN; ++e)
+                    if (code[e] < 0 || v[e] > best[e]) {  // first in-image element initialises; then strictly greater wins
+                        best[e] = v[e];
+                        code[e] = dx;
+                    }
+            }
+            Chunk<T>::store(RM + (size_t)i * 16, best);
+            store_codes<CN>(RC + (size_t)i * CN, code);
+        }
+        __syncthreads();
+        // column pass: arg-max code (dy*k + dx) of the window centred at every position
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int h = i / a.W, w = i - h * a.W;
+            float best[CN];
+            int code[CN];
+#pragma unroll
+            for (int e = 0; e < CN; ++e) { best[e] = NEG_INF; code[e] = -1; }
+            for (int dy = 0; dy < k; ++dy) {
+                const int hh = h + dy - r;
+                if (hh < 0 || hh >= a.H) continue;
+                const size_t rp = (size_t)hh * a.W + w;
+                float v[CN];
+                Chunk<T>::load(RM + rp * 16, v);
+                const uint64_t rc = load_codes<CN>(RC + rp * CN);
+#pragma unroll
+                for (int e = 0; e < CN; ++e)
+                    if (code[e] < 0 || v[e] > best[e]) {
+                        best[e] = v[e];
+                        code[e] = dy * k + (int)((rc >> (8 * e)) & 255);
+                    }
+            }
+            store_codes<CN>(IDX + (size_t)i * CN, code);
+        }
+        __syncthreads();
+        // gather: gnext[s] = dy_st[s] + sum over windows p containing s whose arg-max is s of gcur[p]
+        const T* dp = reinterpret_cast<const T*>(a.dy[st].p);
+        T* op = reinterpret_cast<T*>(a.dy[0].p);
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            const int h = i / a.W, w = i - h * a.W;
+            float acc[CN];
+            Chunk<T>::load(dp + (img + i) * a.dy[st].ld + c0, acc);
+            for (int ay = -r; ay <= r; ++ay) {
+                const int ph = h + ay;
+                if (ph < 0 || ph >= a.H) continue;
+                for (int ax = -r; ax <= r; ++ax) {
+                    const int pw = w + ax;
+                    if (pw < 0 || pw >= a.W) continue;
+                    const int want = (r - ay) * k + (r - ax);
+                    const size_t gp = (size_t)ph * a.W + pw;
+                    const uint64_t ix = load_codes<CN>(IDX + gp * CN);
+#pragma unroll
+                    for (int e = 0; e < CN; ++e)
+                        if ((int)((ix >> (8 * e)) & 255) == want) acc[e] += gcur[gp * CN + e];
+                }
+            }
+            if (st == 0) {
+                Chunk<T>::store(op + (img + i) * a.dy[0].ld + c0, acc);
+            } else {
+#pragma unroll
+                for (int e = 0; e < CN; ++e) gnext[(size_t)i * CN + e] = acc[e];
+            }
+        }
+        __syncthreads();  // gnext complete; X / RM / RC / IDX free for the next stage
+        float* t = gcur;
+        gcur = gnext;
+        gnext = t;
+    }
+}
+
+static size_t sppf_bwd_fused_lds(int hw, int cn) { return (size_t)hw * (2 * cn * sizeof(float) + 16 + 16 + 2 * cn); }
+
 // dy2 += route(dy3 | y2); dy1 += route(dy2 | y1); dy0 += route(dy1 | y0).  dy1 and dy2 are modified in place.
 extern "C" int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, const ymi_tensor* y2, int64_t k, const ymi_tensor* dy1,
                                   const ymi_tensor* dy2, const ymi_tensor* dy3, const ymi_tensor* dy0_accum, void* stream) {
@@ -366,6 +494,20 @@ extern "C" int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, co
     }
     YMI_CHECK_ARG(k >= 1 && (k & 1) && k <= 13, "sppf_pool3_bwd: odd k <= 13");
     hipStream_t s = (hipStream_t)stream;
+    static const int fused_env = getenv("YMI_SPPF_BWD_FUSED") ? atoi(getenv("YMI_SPPF_BWD_FUSED")) : 0;  // 1: all three stages in one launch - measured SLOWER (14.88 vs 14.76 ms/step on the same box: the gather is VALU/LDS-bound, not launch-bound, and the f32 running gradient halves the resident workgroups)
+    const int hw = (int)(y0->h * y0->w);
+    if (fused_env && y0->c % cn == 0 && sppf_bwd_fused_lds(hw, cn) <= 64 * 1024) {  // whole map in LDS (dy1 / dy2 are left untouched)
+        PoolBwd3Args a{};
+        a.y[0] = PV{y0->data, y0->ld}; a.y[1] = PV{y1->data, y1->ld}; a.y[2] = PV{y2->data, y2->ld};
+        a.dy[0] = PV{dy0_accum->data, dy0_accum->ld}; a.dy[1] = PV{dy1->data, dy1->ld}; a.dy[2] = PV{dy2->data, dy2->ld}; a.dy[3] = PV{dy3->data, dy3->ld};
+        a.N = (int)y0->n; a.H = (int)y0->h; a.W = (int)y0->w; a.C = (int)y0->c; a.k = (int)k;
+        const size_t lds = sppf_bwd_fused_lds(hw, cn);
+        dim3 grid((unsigned)(y0->c / cn), (unsigned)y0->n);
+        if (y0->dtype == YMI_BF16) hipLaunchKernelGGL((sppf_bwd_fused_kernel<bf16_t>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((sppf_bwd_fused_kernel<float>), grid, dim3(256), lds, s, a);
+        YMI_CHECK_LAUNCH("sppf_pool3_bwd(fused)");
+        return YMI_OK;
+    }
     int rc = launch_pool_bwd(y2, (int)k, dy3, dy2, s);
     if (rc) return rc;
     rc = launch_pool_bwd(y1, (int)k, dy2, dy1, s);

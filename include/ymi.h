@@ -188,8 +188,8 @@ int ymi_wgrad_reduce_batch(const ymi_wgrad_pending* host_records, int32_t n, ymi
 int ymi_sppf_pool3_fwd(const ymi_tensor* y0, int64_t k, const ymi_tensor* y1, const ymi_tensor* y2, const ymi_tensor* y3, void* stream);
 /* Adjoint of the cascade, stage by stage as a deterministic gather: dy2 += route(dy3|y2);
  * dy1 += route(dy2|y1); dy0 += route(dy1|y0), each window's gradient going to its first arg-max in
- * row-major order (PyTorch's max_pool2d tie rule).  dy1, dy2 are modified in place; dy0 must already
- * hold the direct gradient of y0. */
+ * row-major order (PyTorch's max_pool2d tie rule).  dy1, dy2 may be modified in place (scratch); dy0 must
+ * already hold the direct gradient of y0.  Maps that fit LDS whole run all three stages in one launch. */
 int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, const ymi_tensor* y2, int64_t k, const ymi_tensor* dy1,
                        const ymi_tensor* dy2, const ymi_tensor* dy3, const ymi_tensor* dy0_accum, void* stream);
 
