@@ -128,10 +128,11 @@ class GradientBuckets:
         if self._pending[bi] == 0:
             self._launch(bi)
 
-    def finish(self, grads_of=None):
+    def finish(self, grads_of=None, force=False):
         """wait for every bucket and leave grad = sum / world in .grad (as views of the flat buffers: no copy back);
-        re-arm for the next step.  grads_of: optional {param: gradient tensor} to reduce instead of .grad."""
-        if self.world == 1:
+        re-arm for the next step.  grads_of: optional {param: gradient tensor} to reduce instead of .grad.
+        force: run the collectives even on one rank (the RCCL smoke test of a one-GPU box)."""
+        if self.world == 1 and not force:
             return
         for bi, b in enumerate(self.buckets):
             if self._work[bi] is None:  # no hook fired (overlap off, or parameters without a gradient this step)

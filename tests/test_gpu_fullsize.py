@@ -316,6 +316,64 @@ def test_two_rank_training_keeps_replicas_identical(graph):
     np.testing.assert_allclose(res[0][2], res[1][2], rtol=0, atol=0)
 
 
+def _rccl_worker(port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)  # "nccl" IS RCCL on ROCm
+    from improving_yolov8_cbam_swinblock_amd.engine import ddp
+    from improving_yolov8_cbam_swinblock_amd.engine.trainer import TrainStep, synthetic_batch
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+
+    d = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    model = DetectionModel("yolov8n-cbam.yaml", ch=3, nc=1).to(d)
+    # the flat-bucket broadcast and the bucketed gradient all-reduce through RCCL (one rank: identity, but every call,
+    # buffer and stream hand-off of the multi-GPU schedule runs)
+    flat = torch.arange(1 << 20, dtype=torch.float32, device=d)
+    dist.broadcast(flat, 0)
+    step = TrainStep(model, world_size=1, graph=False)
+    batch = synthetic_batch(2, 320, d, 1)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        loss, _ = model(batch)
+    loss.sum().backward()
+    ref = {n: p.grad.detach().float().clone() for n, p in model.named_parameters() if p.grad is not None}
+    gb = ddp.GradientBuckets(model, 1, bucket_bytes=4 << 20, overlap=False)
+    gb.finish(force=True)
+    torch.cuda.synchronize()
+    ok = all(torch.equal(p.grad.float(), ref[n]) for n, p in model.named_parameters() if n in ref)
+    views = all(p.grad.data_ptr() != 0 for p in model.parameters() if p.grad is not None)
+    q.put((bool(ok), bool(views), len(gb.buckets), float(flat.sum().item())))
+    dist.barrier()
+    dist.destroy_process_group()
+    del step
+
+
+def test_rccl_single_rank_bucketed_allreduce():
+    """the RCCL backend itself (not gloo) under the bucketed gradient mean, on the one GPU of the box: world_size 1, so
+    the all-reduce is the identity - what is checked is that RCCL initialises with the dmabuf IPC setting, accepts the flat
+    f32 buckets as they are built, completes asynchronously and leaves .grad pointing at the reduced buffers."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_worker, args=(port, q))
+    proc.start()
+    ok, views, nb, total = q.get(timeout=300)
+    proc.join(120)
+    assert ok and views and nb >= 2
+    assert total == float(sum(range(1 << 20)))
+
+
 def test_profile_table_lists_every_layer():
     """utils/profile.py: the per-module forward / backward table (reference torch_utils.py:792-870 reporting format)."""
     from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
