@@ -72,6 +72,8 @@ _SIGNATURES = {
     "ymi_bn_act_bwd": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_data": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
     "ymi_conv2d_bwd_data_add": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp]),
+    "ymi_conv2d_bwd_data_bn": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _vp, _c_i64, ctypes.POINTER(ctypes.c_int64), _TP, _vp]),
+    "ymi_bn_act_bwd_from_partials": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _vp, _c_i64, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_swin_mlp_fwd": (_c_i32, [_TP, _vp, _vp, _c_i64, _vp, _vp, _TP, _TP, _TP, _TP, _vp]),
     "ymi_swin_mlp_bwd_data": (_c_i32, [_TP, _vp, _TP, _TP, _vp, _TP, _TP, _TP, _vp]),
     "ymi_conv2d_bwd_weight": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp]),

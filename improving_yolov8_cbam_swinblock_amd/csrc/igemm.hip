@@ -79,6 +79,18 @@ struct IgemmArgs {
     const void* mul;   // optional multiplier: y = value * act'(mul) with mul_act's derivative (GELU backward inside fc2's data gradient)
     int64_t ldy2, ldmul;
     int act2, mul_act;
+    // BatchNorm-backward mode of a data-gradient launch whose output is the gradient dy of a Conv-BN-act producer: the epilogue
+    // stores u = dy * act'(z^) instead of dy (z^ = BN(raw) of the PRODUCER, recomputed from its raw conv output and saved
+    // statistics) and per-workgroup partial sums of u and u * x^ - the reduce pass of that layer's BN backward, without its read
+    // of dy and without its launch.  bn_partials[(mb * 2 + which) * Cout + ch], as the forward statistics.
+    const void* bn_raw;
+    const float* bn_gamma;
+    const float* bn_beta;
+    const float* bn_mean;
+    const float* bn_inv;
+    float* bn_partials;
+    int64_t ldbn;
+    int bn_act;
     const float* scale;
     const float* bias;
     float* partials;
@@ -436,7 +448,78 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         constexpr int EPC = 16 / ES;       // elements per chunk
         const T* mulp = STATS ? nullptr : reinterpret_cast<const T*>(a.mul);
         const bool post = act != YMI_ACT_NONE || res2nd || mulp;  // (workgroup-uniform) something left to do on the stored values
-        if (!post) {
+        const T* bnraw = STATS ? nullptr : reinterpret_cast<const T*>(a.bn_raw);
+        if (bnraw) {
+            // BatchNorm-backward mode (host: no activation / late addends / multiplier in this launch, full 16-byte chunks).
+            // A thread keeps ONE chunk column (NT is a multiple of CPW): its EPC channels' coefficients and sums stay in registers.
+            static_assert(NT % CPW == 0, "a thread keeps one chunk column");
+            const int cc = tid_all % CPW, ch0 = n0 + cc * EPC;
+            const bool cok = ch0 < a.Cout;
+            float a0[EPC], a1[EPC], p0[EPC], p1[EPC], s0[EPC], s1[EPC];
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                const int ch = cok ? ch0 + e : 0;
+                const float g = a.bn_gamma ? a.bn_gamma[ch] : 1.0f, b = a.bn_beta ? a.bn_beta[ch] : 0.0f;
+                p0[e] = a.bn_inv[ch];
+                p1[e] = -a.bn_mean[ch] * p0[e];
+                a0[e] = p0[e] * g;
+                a1[e] = p1[e] * g + b;
+                s0[e] = 0.f;
+                s1[e] = 0.f;
+            }
+            constexpr int RPT = BM * CPW / NT;  // rows per thread
+            // all raw chunks of this thread in flight before the first use
+            u32x4 zraw[RPT];
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int row = tid_all / CPW + q * (NT / CPW);
+                const int m = m0 + row;
+                zraw[q] = (m < a.M && cok) ? *reinterpret_cast<const u32x4*>(bnraw + out_pixel(m) * a.ldbn + ch0) : u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int q = 0; q < RPT; ++q) {
+                const int row = tid_all / CPW + q * (NT / CPW);
+                const int m = m0 + row;
+                if (m < a.M && cok) {
+                    u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
+                    T* vp = reinterpret_cast<T*>(&val);
+                    const T* zp = reinterpret_cast<const T*>(&zraw[q]);
+#pragma unroll
+                    for (int h = 0; h < EPC / 4; ++h) {
+                        float v[4], z[4];
+                        Pack<T, 4>::load(vp + 4 * h, v);
+                        Pack<T, 4>::load(zp + 4 * h, z);
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int e = 4 * h + r;
+                            const float u = v[r] * act_grad_rt(z[r] * a0[e] + a1[e], a.bn_act);
+                            s0[e] += u;
+                            s1[e] += u * (z[r] * p0[e] + p1[e]);
+                            v[r] = u;
+                        }
+                        Pack<T, 4>::store(vp + 4 * h, v);
+                    }
+                    *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch0) = val;
+                }
+            }
+            // per-channel sums of the workgroup: NT / CPW threads share a chunk column; fixed order (deterministic)
+            __syncthreads();  // everyone has read its part of the output image: reuse it
+            float* red2 = reinterpret_cast<float*>(smem);  // [NT / CPW][2][BN]
+            const int rg_ = tid_all / CPW;
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) {
+                red2[(rg_ * 2 + 0) * BN + cc * EPC + e] = s0[e];
+                red2[(rg_ * 2 + 1) * BN + cc * EPC + e] = s1[e];
+            }
+            __syncthreads();
+            if (tid_all < 2 * BN) {
+                const int which = tid_all / BN, chl = tid_all % BN;
+                float sum = 0.f;
+                for (int q = 0; q < NT / CPW; ++q) sum += red2[(q * 2 + which) * BN + chl];
+                const int ch = n0 + chl;
+                if (ch < a.Cout) a.bn_partials[((int64_t)mb * 2 + which) * a.Cout + ch] = sum;
+            }
+        } else if (!post) {
 #pragma unroll 4
             for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
                 const int row = idx / CPW, cc = idx % CPW;
@@ -1345,8 +1428,20 @@ extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_pac
     return ymi_conv2d_bwd_data_add(dy, w_dgrad_packed, cin, kh, kw, stride, nullptr, nullptr, dx, stream);
 }
 
+struct BnBwdFuse {  // BatchNorm-backward mode of a stride-1 data gradient (see IgemmArgs::bn_raw)
+    const ymi_tensor* raw;
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* inv;
+    int32_t act;
+    float* partials;
+    int64_t partial_floats;  // capacity of `partials`
+    int64_t* rows_out;       // partial rows written (host value)
+};
 static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
-                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream);
+                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream,
+                      const BnBwdFuse* bn = nullptr);
 
 extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw,
                                        int64_t stride, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream) {
@@ -1354,8 +1449,17 @@ extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad
 }
 
 static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
-                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream) {
+                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream,
+                      const BnBwdFuse* bn) {
     YMI_CHECK_ARG(ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && w_dgrad_packed, "conv2d_bwd_data: bad tensor");
+    if (bn) {
+        const int epc = (int)(16 / ymi_esize(dx->dtype));
+        YMI_CHECK_ARG(stride == 1 && !mul, "conv2d_bwd_data_bn: stride-1 data gradients only");
+        YMI_CHECK_ARG(ymi_tensor_ok(bn->raw) && ymi_same_shape(bn->raw, dx) && bn->raw->dtype == dx->dtype && bn->mean && bn->inv && bn->partials && bn->rows_out,
+                      "conv2d_bwd_data_bn: the producer's raw output must have the gradient's shape");
+        YMI_CHECK_ARG(dx->ld % epc == 0 && ((uintptr_t)dx->data & 15) == 0 && bn->raw->ld % epc == 0 && ((uintptr_t)bn->raw->data & 15) == 0 && cin % epc == 0,
+                      "conv2d_bwd_data_bn: 16-byte-aligned rows");
+    }
     if (mul) {
         const int epc = (int)(16 / ymi_esize(dx->dtype));
         YMI_CHECK_ARG(ymi_tensor_ok(mul) && ymi_same_shape(mul, dx) && mul->dtype == dx->dtype && mul->ld % 4 == 0 &&
@@ -1402,6 +1506,10 @@ static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t 
             pack_taps(dh, dw, nt, &a.tap_dh, &a.tap_dw);
             a.act = YMI_ACT_NONE;
             a.mul = mul ? mul->data : nullptr; a.ldmul = mul ? mul->ld : 0; a.mul_act = mul_act;
+            if (bn) {
+                a.bn_raw = bn->raw->data; a.ldbn = bn->raw->ld; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_inv = bn->inv;
+                a.bn_act = bn->act; a.bn_partials = bn->partials;
+            }
             a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0) &&
                           (!add1 || (add1->ld % 4 == 0 && ((uintptr_t)add1->data) % (4 * es) == 0)) &&
                           (!add2 || (add2->ld % 4 == 0 && ((uintptr_t)add2->data) % (4 * es) == 0));
@@ -1415,12 +1523,35 @@ static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t 
     }
     static const int fuse_env = getenv("YMI_DGRAD_FUSE") ? atoi(getenv("YMI_DGRAD_FUSE")) : 1;  // 0: one launch per parity class
     // (measured: fusing pays from 64 output channels up; the 32-channel layer 1 is 6 % faster class by class)
+    if (bn) {  // one class (stride 1); the launcher reports the M blocks of the tile it chose = partial rows
+        YMI_CHECK_ARG(nlaunch == 1 && classes[0].vec16, "conv2d_bwd_data_bn: needs the aligned single-launch form");
+        // the smallest tile any choice uses has 64 rows: the caller's buffer must hold that many rows
+        const int64_t worst = ((int64_t)classes[0].M + 63) / 64;
+        YMI_CHECK_ARG(bn->partial_floats >= worst * 2 * cin, "conv2d_bwd_data_bn: partials buffer %lld < %lld floats", (long long)bn->partial_floats,
+                      (long long)(worst * 2 * cin));
+        int blocks = 0;
+        const int rc = launch_igemm_n(classes, 1, dy->dtype, false, &blocks, (hipStream_t)stream);
+        *bn->rows_out = blocks;
+        return rc;
+    }
     if (fuse_env && cin >= 64 && nlaunch > 1) return launch_igemm_n(classes, nlaunch, dy->dtype, false, nullptr, (hipStream_t)stream);
     for (int i = 0; i < nlaunch; ++i) {
         int rc = ymi_launch_igemm(classes[i], dy->dtype, false, nullptr, (hipStream_t)stream);
         if (rc) return rc;
     }
     return YMI_OK;
+}
+
+// Data gradient of a convolution whose INPUT was produced by a Conv-BatchNorm-activation block, with the reduce pass of that
+// block's BatchNorm backward folded into the epilogue (stride 1): dx receives u = (dgrad + add1 + add2) * act'(BN(raw)) and
+// `partials` [rows][2][cin] the per-workgroup sums of u and u * x^; *rows_out = rows written.  ymi_bn_act_bwd_from_partials
+// finishes that layer's backward from them.
+extern "C" int ymi_conv2d_bwd_data_bn(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, const ymi_tensor* add1,
+                                      const ymi_tensor* add2, const ymi_tensor* bn_raw, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                                      const float* bn_invstd, int32_t bn_act, float* partials, int64_t partial_floats, int64_t* rows_out,
+                                      const ymi_tensor* dx, void* stream) {
+    BnBwdFuse bn{bn_raw, bn_gamma, bn_beta, bn_mean, bn_invstd, bn_act, partials, partial_floats, rows_out};
+    return dgrad_impl(dy, w_dgrad_packed, cin, kh, kw, 1, add1, add2, nullptr, YMI_ACT_NONE, dx, stream, &bn);
 }
 
 // ---- SwinBlock MLP (swin_block.py:33,53: Linear(C, 4C) -> GELU -> Linear(4C, C), + the skip) ------------------------------------

@@ -317,31 +317,10 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
     }
 }
 
-extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
-                              const float* save_invstd, const float* beta, int32_t act, const ymi_tensor* draw, float* dgamma,
-                              float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
-    YMI_CHECK_ARG(ymi_tensor_ok(dout) && ymi_tensor_ok(raw) && ymi_tensor_ok(draw) && ymi_same_shape(dout, raw) && ymi_same_shape(dout, draw),
-                  "bn_act_bwd: shapes");
-    YMI_CHECK_ARG(dout->dtype == raw->dtype && raw->dtype == draw->dtype, "bn_act_bwd: dtypes");
-    YMI_CHECK_ARG(save_mean && save_invstd && dgamma && dbeta && workspace, "bn_act_bwd: null argument");
-    YMI_CHECK_ARG(draw->ld % 4 == 0, "bn_act_bwd: draw ld");
+// apply pass of the BN backward: draw = dout * act'(raw * a0 + a1) * c0 - raw * c1 - c2 with coef = [a0|a1|c0|c1|c2][C]
+static int launch_bn_apply(const ymi_tensor* dout, const ymi_tensor* raw, const ymi_tensor* draw, int act, const float* coef, hipStream_t s) {
     const int64_t P = ymi_pixels(dout);
     const int C = (int)dout->c;
-    const int rblocks = reduce_blocks(P, C);
-    const size_t need = ((size_t)rblocks * 2 * C + 5 * (size_t)C) * sizeof(float);
-    if (workspace_bytes < need) {
-        ymi_set_error("bn_act_bwd: workspace %zu < %zu", workspace_bytes, need);
-        return YMI_EWORKSPACE;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    int blocks = 0;
-    int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)");
-    if (rc) return rc;
-    float* coef = (float*)workspace + (size_t)blocks * 2 * C;
-    // dbeta = sum dz, dgamma = sum dz*xhat, and the apply pass's coefficients
-    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)workspace, blocks, C, dbeta, dgamma,
-                       BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef});
-    YMI_CHECK_LAUNCH("bn_act_bwd(final)");
     const bool bf = dout->dtype == YMI_BF16;
     const bool al16 = bf && C % 8 == 0 && dout->ld % 8 == 0 && raw->ld % 8 == 0 && draw->ld % 8 == 0 &&
                       (((uintptr_t)dout->data | (uintptr_t)raw->data | (uintptr_t)draw->data) & 15) == 0;
@@ -381,6 +360,58 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
 #undef YMI_BWD_APPLY
     YMI_CHECK_LAUNCH("bn_act_bwd(apply)");
     return YMI_OK;
+}
+
+extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
+                              const float* save_invstd, const float* beta, int32_t act, const ymi_tensor* draw, float* dgamma,
+                              float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(dout) && ymi_tensor_ok(raw) && ymi_tensor_ok(draw) && ymi_same_shape(dout, raw) && ymi_same_shape(dout, draw),
+                  "bn_act_bwd: shapes");
+    YMI_CHECK_ARG(dout->dtype == raw->dtype && raw->dtype == draw->dtype, "bn_act_bwd: dtypes");
+    YMI_CHECK_ARG(save_mean && save_invstd && dgamma && dbeta && workspace, "bn_act_bwd: null argument");
+    YMI_CHECK_ARG(draw->ld % 4 == 0, "bn_act_bwd: draw ld");
+    const int64_t P = ymi_pixels(dout);
+    const int C = (int)dout->c;
+    const int rblocks = reduce_blocks(P, C);
+    const size_t need = ((size_t)rblocks * 2 * C + 5 * (size_t)C) * sizeof(float);
+    if (workspace_bytes < need) {
+        ymi_set_error("bn_act_bwd: workspace %zu < %zu", workspace_bytes, need);
+        return YMI_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int blocks = 0;
+    int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)");
+    if (rc) return rc;
+    float* coef = (float*)workspace + (size_t)blocks * 2 * C;
+    // dbeta = sum dz, dgamma = sum dz*xhat, and the apply pass's coefficients
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)workspace, blocks, C, dbeta, dgamma,
+                       BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef});
+    YMI_CHECK_LAUNCH("bn_act_bwd(final)");
+    return launch_bn_apply(dout, raw, draw, act, coef, s);
+}
+
+// The rest of a Conv-BN-act block's backward when the data-gradient launch that produced its output gradient already multiplied
+// by act' and left per-workgroup partial sums (ymi_conv2d_bwd_data_bn): final reduce (dbeta, dgamma, apply coefficients) and the
+// apply pass  draw = u * c0 - raw * c1 - c2.  No reduce pass over the tensors.  workspace: 5 * C floats.
+extern "C" int ymi_bn_act_bwd_from_partials(const ymi_tensor* u, const ymi_tensor* raw, const float* gamma, const float* save_mean, const float* save_invstd,
+                                            const float* beta, const float* partials, int64_t rows, const ymi_tensor* draw, float* dgamma, float* dbeta,
+                                            void* workspace, size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(u) && ymi_tensor_ok(raw) && ymi_tensor_ok(draw) && ymi_same_shape(u, raw) && ymi_same_shape(u, draw), "bn_act_bwd_from_partials: shapes");
+    YMI_CHECK_ARG(u->dtype == raw->dtype && raw->dtype == draw->dtype, "bn_act_bwd_from_partials: dtypes");
+    YMI_CHECK_ARG(save_mean && save_invstd && dgamma && dbeta && partials && workspace && rows > 0, "bn_act_bwd_from_partials: null argument");
+    const int64_t P = ymi_pixels(u);
+    const int C = (int)u->c;
+    YMI_CHECK_ARG(C % 4 == 0 && u->ld % 4 == 0 && raw->ld % 4 == 0 && draw->ld % 4 == 0, "bn_act_bwd_from_partials: channels must be a multiple of 4");
+    if (workspace_bytes < 5 * (size_t)C * sizeof(float)) {
+        ymi_set_error("bn_act_bwd_from_partials: workspace %zu < %zu", workspace_bytes, 5 * (size_t)C * sizeof(float));
+        return YMI_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* coef = (float*)workspace;
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, partials, (int)rows, C, dbeta, dgamma,
+                       BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef});
+    YMI_CHECK_LAUNCH("bn_act_bwd_from_partials(final)");
+    return launch_bn_apply(u, raw, draw, YMI_ACT_NONE, coef, s);
 }
 
 // dx = dy * gelu'(pre)

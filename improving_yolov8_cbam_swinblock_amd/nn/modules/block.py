@@ -37,7 +37,10 @@ class Bottleneck(nn.Module):
         x = ops.to_internal(x)
         if self.add and self.training and ops.join_of(x) is None:
             ops.mark_join(x, 2)  # consumers of x here: cv1 and the shortcut; their gradient sum forms in cv1's data-gradient epilogue
-        return self.cv2(self.cv1(x), residual=x if self.add else None, out=out)
+        h = self.cv1(x)
+        if self.training:
+            ops.mark_sole(h)  # h feeds cv2 only: cv2's data gradient may carry the reduce pass of cv1's BatchNorm backward
+        return self.cv2(h, residual=x if self.add else None, out=out)
 
 
 class C2f(nn.Module):

@@ -66,13 +66,23 @@ class Detect(nn.Module):
         self.cv3 = nn.ModuleList(nn.Sequential(Conv(x, c3, 3), Conv(c3, c3, 3), _Out1x1(c3, self.nc, 1)) for x in ch)
         self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
 
+    def _branch(self, seq, xi):
+        """Conv -> Conv -> biased 1x1 (head.py:45-59); each intermediate map has exactly one consumer, so in training the next
+        convolution's data gradient carries the reduce pass of the previous block's BatchNorm backward (ops.mark_sole)."""
+        h = xi
+        for j, m in enumerate(seq):
+            h = m(h)
+            if self.training and j + 1 < len(seq):
+                ops.mark_sole(h)
+        return h
+
     def forward(self, x):
         x = list(x)
         box, cls = [], []
         for i in range(self.nl):
             xi = ops.to_internal(x[i])
-            box.append(self.cv2[i](xi))
-            cls.append(self.cv3[i](xi))
+            box.append(self._branch(self.cv2[i], xi))
+            cls.append(self._branch(self.cv3[i], xi))
             x[i] = ops.concat([box[i], cls[i]])
         if self.training:
             return x
@@ -86,8 +96,8 @@ class Detect(nn.Module):
         box, cls = [], []
         for i in range(self.nl):
             xi = ops.to_internal(x[i])
-            box.append(self.cv2[i](xi))
-            cls.append(self.cv3[i](xi))
+            box.append(self._branch(self.cv2[i], xi))
+            cls.append(self._branch(self.cv3[i], xi))
         return box, cls
 
     def _inference(self, box, cls=None):
