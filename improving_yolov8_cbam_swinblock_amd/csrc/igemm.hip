@@ -317,7 +317,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines (per-lane 8-byte stores
 // to 16 different rows cost 2-3x the time of the same bytes stored this way).  STATS: raw output + deterministic
 // per-block BatchNorm partial sums; otherwise scale / bias / activation / up to two addends.
-template <typename T, int BM, int BN, int WM, int WN, bool STATS, int NT>
+template <typename T, int BM, int BN, int WM, int WN, bool STATS, int NT, bool BNB = false>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], char* smem, int m0, int n0, int mb, int wm,
                                                int wn, int lane, int tid_all, bool consumer
 #ifdef YMI_STAMPS
@@ -448,8 +448,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         constexpr int EPC = 16 / ES;       // elements per chunk
         const T* mulp = STATS ? nullptr : reinterpret_cast<const T*>(a.mul);
         const bool post = act != YMI_ACT_NONE || res2nd || mulp;  // (workgroup-uniform) something left to do on the stored values
-        const T* bnraw = STATS ? nullptr : reinterpret_cast<const T*>(a.bn_raw);
-        if (bnraw) {
+        // (BNB: the BatchNorm-backward mode is its own instantiation - compiled into every data-gradient kernel its extra kernel
+        // arguments and registers cost the ordinary path 4 % through scalar-register spills)
+        const T* bnraw = (BNB && !STATS) ? reinterpret_cast<const T*>(a.bn_raw) : nullptr;
+        if constexpr (BNB && !STATS) {
             // BatchNorm-backward mode (host: no activation / late addends / multiplier in this launch, full 16-byte chunks).
             // A thread keeps ONE chunk column (NT is a multiple of CPW): its EPC channels' coefficients and sums stay in registers.
             static_assert(NT % CPW == 0, "a thread keeps one chunk column");
@@ -468,22 +470,25 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
                 s1[e] = 0.f;
             }
             constexpr int RPT = BM * CPW / NT;  // rows per thread
-            // all raw chunks of this thread in flight before the first use
-            u32x4 zraw[RPT];
-#pragma unroll
+            // One row per trip, NOT unrolled, the next row's raw chunk in flight while this one is processed: this block exists in
+            // every data-gradient kernel and must stay small (unrolled 8x with both activation derivatives inlined it was 10,000
+            // instructions and cost the ordinary path 4 %).  Only SiLU / none occur behind a BatchNorm (the host checks).
+            const bool silu = a.bn_act == YMI_ACT_SILU;
+            auto zload = [&](int q) -> u32x4 {
+                const int m = m0 + tid_all / CPW + q * (NT / CPW);
+                return (q < RPT && m < a.M && cok) ? *reinterpret_cast<const u32x4*>(bnraw + out_pixel(m) * a.ldbn + ch0) : u32x4{0u, 0u, 0u, 0u};
+            };
+            u32x4 znext = zload(0);
+#pragma unroll 1
             for (int q = 0; q < RPT; ++q) {
-                const int row = tid_all / CPW + q * (NT / CPW);
-                const int m = m0 + row;
-                zraw[q] = (m < a.M && cok) ? *reinterpret_cast<const u32x4*>(bnraw + out_pixel(m) * a.ldbn + ch0) : u32x4{0u, 0u, 0u, 0u};
-            }
-#pragma unroll
-            for (int q = 0; q < RPT; ++q) {
+                const u32x4 zcur = znext;
+                znext = zload(q + 1);
                 const int row = tid_all / CPW + q * (NT / CPW);
                 const int m = m0 + row;
                 if (m < a.M && cok) {
                     u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
                     T* vp = reinterpret_cast<T*>(&val);
-                    const T* zp = reinterpret_cast<const T*>(&zraw[q]);
+                    const T* zp = reinterpret_cast<const T*>(&zcur);
 #pragma unroll
                     for (int h = 0; h < EPC / 4; ++h) {
                         float v[4], z[4];
@@ -492,7 +497,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
                             const int e = 4 * h + r;
-                            const float u = v[r] * act_grad_rt(z[r] * a0[e] + a1[e], a.bn_act);
+                            const float g = silu_grad_f(z[r] * a0[e] + a1[e]);
+                            const float u = v[r] * (silu ? g : 1.0f);
                             s0[e] += u;
                             s1[e] += u * (z[r] * p0[e] + p1[e]);
                             v[r] = u;
@@ -519,7 +525,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
                 const int ch = n0 + chl;
                 if (ch < a.Cout) a.bn_partials[((int64_t)mb * 2 + which) * a.Cout + ch] = sum;
             }
-        } else if (!post) {
+        } else
+        if (!post) {
 #pragma unroll 4
             for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
                 const int row = idx / CPW, cc = idx % CPW;
@@ -627,7 +634,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 // barrier, so each SIMD always holds one wave in its memory phase beside one in its compute phase (the arrangement
 // MI355X_MICROARCH.md, Two waves per SIMD, describes) instead of two waves in the same phase.  Three LDS stages: the pieces
 // of step k+2 overwrite the stage of step k-1, which both halves finished reading at least one phase earlier.
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false, int NTHR = (SPEC ? 512 : 256), bool PP = false>
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false, int NTHR = (SPEC ? 512 : 256), bool PP = false, bool BNB = false>
 __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
@@ -968,9 +975,9 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     // workgroup stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines
     // (per-lane 8-byte stores to 16 different rows cost 2-3x the time of the same bytes stored this way).
 #ifdef YMI_STAMPS
-    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer, stamp_on, wave_all, stamp_mt0);
+    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT, BNB>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer, stamp_on, wave_all, stamp_mt0);
 #else
-    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer);
+    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT, BNB>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YMI_STAMP_MARK(2);  // epilogue done, stores retired
@@ -1202,6 +1209,16 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     } while (0)
 #define YMI_LAUNCH(BM, BN, WM, WN)                                                              \
     do {                                                                                        \
+        if constexpr (!STATS) {                                                                 \
+            if (a.bn_raw) { /* BatchNorm-backward epilogue: its own instantiations of the default form */ \
+                if constexpr (std::is_same<T, bf16_t>::value) {                                 \
+                    if (wide) { YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, false, false, 256, false, true>)); break; } \
+                }                                                                               \
+                if (fast) YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, true, false, false, 256, false, true>)); \
+                else YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, false, false, false, 256, false, true>)); \
+                break;                                                                          \
+            }                                                                                   \
+        }                                                                                       \
         if constexpr (std::is_same<T, bf16_t>::value) {                                         \
             if (spec && spec_ns == 2) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS, true>)); break; } \
             if (spec) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 3, 8, true, STATS, true>)); break; } \
@@ -1455,6 +1472,7 @@ static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t 
     if (bn) {
         const int epc = (int)(16 / ymi_esize(dx->dtype));
         YMI_CHECK_ARG(stride == 1 && !mul, "conv2d_bwd_data_bn: stride-1 data gradients only");
+        YMI_CHECK_ARG(bn->act == YMI_ACT_SILU || bn->act == YMI_ACT_NONE, "conv2d_bwd_data_bn: activation must be SiLU or none");
         YMI_CHECK_ARG(ymi_tensor_ok(bn->raw) && ymi_same_shape(bn->raw, dx) && bn->raw->dtype == dx->dtype && bn->mean && bn->inv && bn->partials && bn->rows_out,
                       "conv2d_bwd_data_bn: the producer's raw output must have the gradient's shape");
         YMI_CHECK_ARG(dx->ld % epc == 0 && ((uintptr_t)dx->data & 15) == 0 && bn->raw->ld % epc == 0 && ((uintptr_t)bn->raw->data & 15) == 0 && cin % epc == 0,
