@@ -824,7 +824,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     const bool b_wave = (BN >= RPI) || (wave * RPW < BN);
     const int nkt = (a.KC + CPR - 1) / CPR;
     if constexpr (PP) {
-        static_assert(NTHR == 512 && NS == 3 && !SPEC && FAST && CPR == 8 && std::is_same<T, bf16_t>::value && WM == 4, "ping-pong form: 512 threads, 3 stages, bf16, 128-byte rows");
+        static_assert(NTHR == 512 && NS == 3 && !SPEC && FAST && std::is_same<T, bf16_t>::value && WM == 4, "ping-pong form: 512 threads, 3 stages, bf16");
         const int half = wave_all >> 2;  // 0: rows 0..BM/2-1 (starts first), 1: the other rows, half a step behind
         bf16x8 wf[CPR / 4][TN], xf[CPR / 4][TM];
         issue(0);
@@ -1153,7 +1153,9 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats,
         t.bm = 256; t.bn = 128;
     }
     // ping-pong form of the same tile (the two 128-row halves half a K step apart), where it leaves >= `pp_env` workgroups
-    static const int pp_env = getenv("YMI_IGEMM_PP") ? atoi(getenv("YMI_IGEMM_PP")) : 0;
+    // Default ON from 300 workgroups (measured, profiles/r02_conv_bench_pp64.txt: with 64-byte rows - three 24 KB stages, TWO resident
+    // workgroups per CU - it wins 5-19 % on every layer that yields >= 400 such tiles and loses 15-25 % at 200; step 14.71 -> 14.38 ms).
+    static const int pp_env = getenv("YMI_IGEMM_PP") ? atoi(getenv("YMI_IGEMM_PP")) : 300;
     if (pp_env > 0 && stats_bf16_hint && cout >= 128 && ktot % 64 == 0 && blocks(256, 128) >= pp_env) {
         t.bm = 256; t.bn = 128; t.pp = true;
     }
@@ -1236,7 +1238,12 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
             static const int big_ns = getenv("YMI_IGEMM_BIG_NS") ? atoi(getenv("YMI_IGEMM_BIG_NS")) : 2;  // ring depth of the 256x128 tile (3: 144 KB of LDS, two K steps in flight)
             lds = (size_t)(big_ns == 3 ? 3 : 2) * (256 + 128) * 128;
             if (epi > lds) lds = epi;
-            if (t.pp) {
+            static const int pp_rowb = getenv("YMI_IGEMM_PP_ROWB") ? atoi(getenv("YMI_IGEMM_PP_ROWB")) : 64;  // 64 (default): 32-deep K steps, 72 KB of LDS, two workgroups per CU; 128: one (slower)
+            if (t.pp && pp_rowb == 64) {
+                lds = (size_t)3 * (256 + 128) * 64;
+                if (epi > lds) lds = epi;
+                YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 4, true, STATS, false, 512, true>));
+            } else if (t.pp) {
                 lds = (size_t)3 * (256 + 128) * 128;
                 YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512, true>));
             } else if (big_ns == 3) YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512>));
