@@ -845,7 +845,10 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
         // The pieces of step k+2 are split between the two phases of step k (stamps, profiles/r02_igemm_phase_stamps.txt: with all
         // six in the memory phase it lasted ~1000 cycles against ~500 of MFMAs): the A rows go out in the memory phase, the
         // weight rows between the MFMAs, and the pointer / tap bookkeeping follows the last MFMA, outside the memory phase.
-        constexpr int NMEM = NA;           // pieces issued in the memory phase (pieces are numbered A rows first)
+#ifndef YMI_PP_ALLMEM
+#define YMI_PP_ALLMEM 0
+#endif
+        constexpr int NMEM = YMI_PP_ALLMEM ? NA + NB : NA;  // pieces issued in the memory phase (pieces are numbered A rows first)
         constexpr int NPC = NA + NB;       // pieces per wave and step
         constexpr int NM = (CPR / 4) * TN * TM;
         auto load_piece = [&](int s, auto pc) {  // piece p of the step whose stage is s, WITHOUT advancing the pointers
