@@ -62,7 +62,8 @@ def test_product_does_not_import_the_oracle():
         src = p.read_text()
         assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), p
     for p in (PKG / "csrc").glob("*"):
-        assert "oracle" not in p.read_text(errors="ignore"), p
+        if p.is_file() and p.suffix in (".hip", ".h", ".cpp", ".c", ""):  # sources and the Makefile (objects / stray tool caches are not product text)
+            assert "oracle" not in p.read_text(errors="ignore"), p
 
 
 def test_parse_model_tables_and_state_dict_keys():
