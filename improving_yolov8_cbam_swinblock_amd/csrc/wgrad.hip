@@ -34,7 +34,7 @@ extern "C" int ymi_debug_stamp_buffer_wgrad(void* p) {
 #endif
 
 #ifdef YMI_STAMPS
-#define WG_STAMP_LDS 2048
+#define WG_STAMP_LDS 4096
 #else
 #define WG_STAMP_LDS 0
 #endif
@@ -133,15 +133,16 @@ template <> struct WFrag<float> {
 
 // BM = output channels per workgroup tile: 64, or 128 for layers with >= 128 output channels (16 instead of 8 MFMAs per
 // wave and K step against the same address arithmetic: the K loop is instruction-issue-bound, not MFMA-bound)
-// BNW = (tap, ci) columns per workgroup tile: 128, or 256 with BM = 128 (experiment: a 128x256 tile moves 24 KB per K step for
-// twice the MFMAs of the 128x128 tile's 16 KB; 64x128 wave tiles, 128 accumulator registers, two workgroups per CU.  Slower, see
-// wgrad_bn).
-template <typename T, int NS, int BM, int BNW = WG_BN>
-__global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
+// BNW = (tap, ci) columns per workgroup tile: 128, or 256 with BM = 128 as a 512-thread workgroup (eight waves in a 2 x 4 grid of
+// 64x64 wave tiles: a 128x256 tile moves 24 KB per K step for twice the MFMAs of the 128x128 tile's 16 KB at the same registers
+// per wave; see wgrad_bn for the measurements).
+template <typename T, int NS, int BM, int BNW = WG_BN, int NT = (BNW == 256 ? 512 : 256)>
+__global__ __launch_bounds__(NT, (BNW == 256 ? 4 : BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
     constexpr int YCW = BM * ES / 16, XCW = BNW * ES / 16;            // 16-byte chunks per tile row
-    constexpr int NY = WG_BK * YCW / 256, NX = WG_BK * XCW / 256;     // chunks per thread per K step
+    constexpr int NY = WG_BK * YCW / NT, NX = WG_BK * XCW / NT;       // chunks per thread per K step
+    constexpr int WCOLS = BNW / 64, WROWS = (NT / 64) / WCOLS;        // wave grid: every wave owns a (BM / WROWS) x 64 tile
     constexpr int YBYTES = WG_BK * BM * ES, XBYTES = WG_BK * BNW * ES;
     constexpr int STAGE = YBYTES + XBYTES;
     static_assert(NY >= 1 && NX >= 1, "tile too small");
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wr = wave >> 1, wc = wave & 1;
+    const int wr = wave / WCOLS, wc = wave % WCOLS;
 #ifdef YMI_STAMPS
     const bool wstamp_on = g_wstamp_buf && blockIdx.x == gridDim.x / 2 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0;
     const unsigned long long wstamp_mt0 = wstamp_on ? __builtin_amdgcn_s_memtime() : 0ull, wstamp_rt0 = wstamp_on ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -184,7 +185,8 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
     // 256-column tile: a block-wide load instruction covers 8 rows, so piece i would start at row 8 i and flip row bit 3 - which the
     // swizzle uses.  Its pieces go to rows  2 (wave & 1) + 8 (wave >> 1) + 4 (i & 1) + 16 (i >> 1) + (lane >> 5)  instead: row
     // bits 0, 1 and 3 come from the thread, bits 2 and 4 from the piece, and the thread's source column chunk stays fixed.
-    const int xrow0 = BNW == 256 ? 2 * (wave & 1) + 8 * (wave >> 1) + (lane >> 5) : tid / XCW;
+    static_assert(NT / XCW >= 16 || BNW != 256, "a block-wide load covers >= 16 rows, so a thread's rows share the row bits the swizzle uses");
+    const int xrow0 = tid / XCW;
     const int xcc = SWZ ? ((tid % XCW) ^ (wg_swz_x(xrow0) << 1)) : (tid % XCW);
     const int j = j0 + xcc * CH;
     const bool x_cok = j < a.NG;
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
     uint32_t x_off[NX];
 #pragma unroll
     for (int i = 0; i < NX; ++i) {
-        const int row = BNW == 256 ? xrow0 + 4 * (i & 1) + 16 * (i >> 1) : tid / XCW + i * (256 / XCW);
+        const int row = tid / XCW + i * (NT / XCW);
         const int m = m_begin + row;
         const int t = wg_fast_div(m, a.wo_mul, a.wo_shr);
         const int wo = m - t * a.Wo;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
     uint32_t y_off[NY];
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-        y_row[i] = tid / YCW + i * (256 / YCW);
+        y_row[i] = tid / YCW + i * (NT / YCW);
         y_off[i] = (uint32_t)((m_begin + y_row[i]) * ldy32 + co0 + ycc * CH);
     }
     const uint32_t y_step = (uint32_t)(WG_BK * ldy32);
@@ -236,19 +238,14 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
         for (int i = 0; i < NY; ++i) {
             const bool ok = y_cok && y_row[i] < left;
             const T* src = ok ? yg + y_off[i] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * 256 + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * NT + wave * 64) * 16), 16, 0, 0);
             y_off[i] += y_step;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const bool ok = x_cok && x_row[i] < left && (unsigned)(x_hs[i] + dh) < (unsigned)a.H && (unsigned)(x_ws[i] + dw) < (unsigned)a.W;
             const T* src = ok ? xg + x_off[i] : zero;
-            if constexpr (BNW == 256) {
-                const int rb = 2 * (wave & 1) + 8 * (wave >> 1) + 4 * (i & 1) + 16 * (i >> 1);  // the wave's two rows rb, rb + 1 are 1 KB of LDS
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + rb * (BNW * ES)), 16, 0, 0);
-            } else {
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * 256 + wave * 64) * 16), 16, 0, 0);
-            }
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * NT + wave * 64) * 16), 16, 0, 0);
             // one K step on
             x_ws[i] += r_ * s_;
             x_hs[i] += q_ * s_;
@@ -265,7 +262,7 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
         }
     };
 
-    constexpr int TR = BM / 32, TC = BNW / 32;  // per wave: BM/2 rows x BNW/2 cols
+    constexpr int TR = BM / WROWS / 16, TC = 4;  // per wave: BM / WROWS rows x 64 cols
     f32x4 acc[TR][TC];
 #pragma unroll
     for (int r = 0; r < TR; ++r)
@@ -295,7 +292,7 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, m_begin + (kt + NS - 1) * WG_BK);
         WG_STEP_STAMP();  // 2: pieces issued
         const char* Ys = smem + (kt % NS) * STAGE;
-        WFrag<T>::template step<BM, TR, TC, BNW>(Ys, Ys + YBYTES, wr * (BM / 2), wc * (BNW / 2), lane, acc);
+        WFrag<T>::template step<BM, TR, TC, BNW>(Ys, Ys + YBYTES, wr * (BM / WROWS), wc * 64, lane, acc);
         WG_STEP_STAMP();  // 3: fragments read, MFMAs issued
     }
 
@@ -313,10 +310,10 @@ __global__ __launch_bounds__(256, (BNW == 256 ? 2 : BM == 128 ? 3 : YMI_WGRAD_WA
     const int l15 = lane & 15, l4 = lane >> 4;
 #pragma unroll
     for (int r = 0; r < TR; ++r) {
-        const int co = co0 + wr * (BM / 2) + r * 16 + l15;
+        const int co = co0 + wr * (BM / WROWS) + r * 16 + l15;
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
-            const int col = j0 + wc * (BNW / 2) + c * 16 + 4 * l4;
+            const int col = j0 + wc * 64 + c * 16 + 4 * l4;
             if (co < a.CoutP && col < a.NG) *reinterpret_cast<f32x4*>(slab + (int64_t)co * a.NG + col) = acc[r][c];
         }
     }
@@ -463,9 +460,10 @@ static int wgrad_bm(int64_t coutp, bool bf16) {
     if (!bf16 || env != 128) return 64;
     return (coutp >= 128 && coutp % 128 == 0) || coutp >= 256 ? 128 : 64;
 }
-// column-tile choice.  YMI_WGRAD_BN=256 selects the 128x256 tile wherever the (tap, ci) axis has at least 256 columns: measured
-// 1.1-1.66x SLOWER than 128x128 on every such layer (profiles/r02_conv_bench_wgrad256.txt) although it moves 0.75x the bytes
-// per FLOP - two resident workgroups instead of three, 204 registers; kept as a knob, off by default.
+// column-tile choice.  YMI_WGRAD_BN=256 selects the 128x256 tile wherever the (tap, ci) axis has at least 256 columns.  Measured
+// SLOWER although it moves 0.75x the bytes per FLOP (profiles/r02_conv_bench_wgrad256.txt): 1.1-1.66x as four waves with 64x128
+// wave tiles (204 registers), and still 1.17x over the model as eight waves with 64x64 wave tiles (116 registers, two workgroups
+// per CU) - the form that made the same tile win in igemm.  Kept as a knob, off by default.
 static int wgrad_bn(int bm, int64_t ng, bool bf16) {
     static const int env = getenv("YMI_WGRAD_BN") ? atoi(getenv("YMI_WGRAD_BN")) : 128;
     return (bf16 && env == 256 && bm == 128 && ng >= 256) ? 256 : WG_BN;
@@ -597,7 +595,7 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
         static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
         const size_t lds = (size_t)ns * (size_t)(WG_BK * (bm + WG_BN) * 2);
         if (bn == 256) {
-            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128, 256>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + 256) * 2) + WG_STAMP_LDS, s, a);
+            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128, 256>), grid, dim3(512), (size_t)2 * (WG_BK * (128 + 256) * 2) + WG_STAMP_LDS, s, a);
         } else if (bm == 128) {
             hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
         } else {
