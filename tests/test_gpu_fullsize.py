@@ -15,7 +15,10 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("cin,cout,k,s,hw", [(32, 64, 3, 2, 64), (64, 64, 3, 1, 40), (96, 64, 1, 1, 40), (256, 128, 1, 1, 20), (128, 256, 3, 2, 40),
-                                             (64, 64, 3, 2, 21), (64, 128, 3, 2, 37)])  # odd sizes: the stride-2 parity classes differ in size
+                                             (64, 64, 3, 2, 21), (64, 128, 3, 2, 37),  # odd sizes: the stride-2 parity classes differ in size
+                                             # >= 300 tiles of 256x128: the ping-pong form of igemm_kernel (bf16), forward and data gradient,
+                                             # with a ragged last tile; 1x1; and the four parity classes of a stride-2 data gradient in one launch
+                                             (128, 128, 3, 1, 141), (256, 256, 1, 1, 100), (128, 256, 3, 2, 200)])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
 def test_conv_block_vs_oracle_midsize(cin, cout, k, s, hw, dtype):
     """multi-tile shapes (several M/N blocks, K loops over all taps) against the CPU oracle, fwd + all grads."""
