@@ -1236,7 +1236,9 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     } while (0)
     if (t.bm == 256 && t.bn == 128) {
         if constexpr (std::is_same<T, bf16_t>::value) {
-            YMI_CHECK_ARG(wide, "igemm: the 256x128 tile needs 128-byte operand rows");
+            static const int pp_rowb_chk = getenv("YMI_IGEMM_PP_ROWB") ? atoi(getenv("YMI_IGEMM_PP_ROWB")) : 64;
+            if (t.pp && pp_rowb_chk == 64) YMI_CHECK_ARG(fast, "igemm: the ping-pong tile needs input channels that are a multiple of 32");
+            else YMI_CHECK_ARG(wide, "igemm: the 256x128 tile needs 128-byte operand rows");
             nthreads = 512;
             static const int big_ns = getenv("YMI_IGEMM_BIG_NS") ? atoi(getenv("YMI_IGEMM_BIG_NS")) : 2;  // ring depth of the 256x128 tile (3: 144 KB of LDS, two K steps in flight)
             lds = (size_t)(big_ns == 3 ? 3 : 2) * (256 + 128) * 128;
