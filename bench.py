@@ -32,8 +32,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-GFLOP_PER_IMG_FWD_BWD = 103.87  # SURVEY.md section 8(d), measured on the reference with FlopCounterMode
-GFLOP_PER_IMG_FWD = 34.68
+# GFLOP per image (2 x MAC over conv / linear / bmm), measured on the reference with FlopCounterMode: SURVEY.md section 8(d) /
+# BASELINE.md section 2.  (model yaml) -> (image size it was measured at, forward, forward + backward); convolutions and
+# window attention both scale with the pixel count, so other sizes scale by (imgsz / size)^2.
+GFLOP_TABLE = {
+    "yolov8s.yaml": (640, 34.68, 103.87),                   # configs 3 / 4
+    "yolov8m-cbam-swin384.yaml": (1280, 368.38, 1104.08),   # config 5
+    "yolov8n-cbam.yaml": (640, 8.08, 24.16),                # config 2
+    "yolov8n-stock.yaml": (640, 8.74, 26.14),               # config 1
+}
+
+
+def gflop_per_img(model, imgsz):
+    """-> (forward, forward + backward) GFLOP per image, or (None, None) for a model without a measured figure."""
+    if model not in GFLOP_TABLE:
+        return None, None
+    size, fwd, both = GFLOP_TABLE[model]
+    k = (imgsz / size) ** 2
+    return fwd * k, both * k
+
+
 PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md)
 HOST_SHARE = 16  # host cores that belong to one GPU of the box (the pool's rule for worker sizing)
 
@@ -148,7 +166,7 @@ def traffic_record(family):
     return best
 
 
-def forward_record(model, batch, steps):
+def forward_record(model, batch, steps, gf_fwd):
     """north_star's target metric: the train-mode forward of the step alone (bf16 autocast, batch statistics, tensors
     saved for backward, weight pack included), replayed as a HIP graph; 1.110 TFLOP per batch of 32."""
     model.train()
@@ -174,7 +192,7 @@ def forward_record(model, batch, steps):
     ms = (time.perf_counter() - t0) / steps * 1e3
     del g
     n = batch["img"].shape[0]
-    tf = n * GFLOP_PER_IMG_FWD / 1e3 / (ms * 1e-3)
+    tf = n * gf_fwd / 1e3 / (ms * 1e-3)
     return {"ms": round(ms, 3), "images_per_sec": round(n / (ms * 1e-3), 1), "tflops": round(tf, 1), "mfma_frac": round(tf / PEAK_BF16_TFLOPS, 4),
             "target_mfma_frac": 0.40, "what": f"train-mode forward (Detect maps), bs={n}, bf16, HIP-graph replay, {steps} timed replays"}
 
@@ -191,6 +209,10 @@ def main():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-forward", action="store_true", help="skip the forward-only sub-record")
     ap.add_argument("--graph", type=int, default=1, help="1: replay the step as a HIP graph (several ranks: forward+backward graph, RCCL mean + update eager), 0: eager")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="torch.distributed backend of the gradient mean: nccl (= RCCL over xGMI, the measured configuration) or gloo "
+                         "(rehearsal of the multi-rank path on fewer GPUs than ranks: ranks then share devices round-robin)")
+    ap.add_argument("--sustained", type=int, default=200, help="graph replays of the sustained-throughput sub-record (0: skip)")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -201,13 +223,19 @@ def main():
     from improving_yolov8_cbam_swinblock_amd.engine.trainer import TrainStep, synthetic_batch
     from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
 
-    rank, local, world = ddp.setup()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    local_env = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.backend == "nccl" and local_env >= ndev:
+        raise SystemExit(f"--backend nccl needs one GPU per rank (LOCAL_RANK {local_env}, {ndev} visible): RCCL refuses ranks that share a device; "
+                         "use --backend gloo to rehearse the multi-rank path on fewer GPUs")
+    device_index = local_env % ndev  # gloo rehearsal: ranks share the visible devices round-robin
+    torch.cuda.set_device(device_index)
+    rank, local, world = ddp.setup(args.backend, device_index=device_index)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    dev = torch.device("cuda", device_index)
 
     torch.manual_seed(0)
     model = DetectionModel(args.model, ch=3, nc=1).to(dev)
@@ -285,9 +313,30 @@ def main():
         torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         dt = float(tmax.item())
     value = args.gpus * args.batch * args.steps / dt
+    sustained = None
+    if use_graph and args.sustained > 0:
+        # the same step, replayed back to back for seconds instead of the K timed steps (0.3 s at the defaults): long enough for an
+        # external sampler (rocm-smi, the driver's GPU-busy probe) to see the device busy and for the clock to settle; same formula
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        ts = time.perf_counter()
+        for _ in range(args.sustained):
+            step(batch)
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+        dts = time.perf_counter() - ts
+        if world > 1:
+            tm = torch.tensor([dts], dtype=torch.float64, device=dev)
+            torch.distributed.all_reduce(tm, op=torch.distributed.ReduceOp.MAX)
+            dts = float(tm.item())
+        sustained = {"steps": args.sustained, "seconds": round(dts, 3), "ms_per_step": round(dts / args.sustained * 1e3, 3),
+                     "images_per_sec": round(args.gpus * args.batch * args.sustained / dts, 2)}
     fwd = None
-    if rank == 0 and not args.no_forward and args.model == "yolov8s.yaml":
-        fwd = forward_record(model, batch, max(args.steps, 10))
+    gf_fwd, gf_both = gflop_per_img(args.model, args.imgsz)
+    if rank == 0 and not args.no_forward and gf_fwd is not None:
+        fwd = forward_record(model, batch, max(args.steps, 10), gf_fwd)
     if rank == 0:
         out = {
             # BASELINE.json's metric on its configuration; other --model / --batch / --imgsz values are named as they are
@@ -305,16 +354,21 @@ def main():
             "dtype": "bf16",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.model} (CBAM + 2x SwinBlock + SPPF5 + SPPF7, nc=1) forward + v8 loss + backward + clip + SGD-nesterov + EMA step, bs={args.batch}/GPU {args.imgsz}x{args.imgsz}",
+                "workload": f"{args.model} (nc=1) forward + v8 loss + backward + clip + SGD-nesterov + EMA step, bs={args.batch}/GPU {args.imgsz}x{args.imgsz}"
+                            + (" (CBAM + 2x SwinBlock + SPPF5 + SPPF7)" if args.model in ("yolov8s.yaml", "yolov8m-cbam-swin384.yaml") else ""),
                 "global_batch": args.batch * args.gpus,
                 "imgsz": args.imgsz,
                 "parallelism": f"dp{args.gpus}",
+                "backend": ("rccl" if args.backend == "nccl" else "gloo") if args.gpus > 1 else None,
             },
             "hip_graph": bool(use_graph),
-            "model_tflops": round(value * GFLOP_PER_IMG_FWD_BWD / 1e3, 2),
-            "model_mfma_frac": round(value * GFLOP_PER_IMG_FWD_BWD / 1e3 / (PEAK_BF16_TFLOPS * args.gpus), 4),
+            "gflop_per_image": round(gf_both, 2) if gf_both is not None else None,
+            "model_tflops": round(value * gf_both / 1e3, 2) if gf_both is not None else None,
+            "model_mfma_frac": round(value * gf_both / 1e3 / (PEAK_BF16_TFLOPS * args.gpus), 4) if gf_both is not None else None,
             "loss_items": [round(float(v), 4) for v in items],
         }
+        if sustained:
+            out["sustained"] = sustained
         if roof:
             out["roofline"] = roof
         if fwd:

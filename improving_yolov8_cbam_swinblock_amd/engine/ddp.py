@@ -20,14 +20,15 @@ def shard_seed(base, rank):
     return int(base) + int(rank)
 
 
-def setup(backend=None):
-    """init the process group from torchrun's environment (reference _setup_ddp, trainer.py:221-232)."""
+def setup(backend=None, device_index=None):
+    """init the process group from torchrun's environment (reference _setup_ddp, trainer.py:221-232: NCCL if available, else
+    Gloo).  device_index: the GPU this rank uses (default LOCAL_RANK; a gloo rehearsal may place several ranks on one device)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         if torch.cuda.is_available():
-            torch.cuda.set_device(local)
+            torch.cuda.set_device(local if device_index is None else device_index)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL buffer sharing)
         dist.init_process_group(backend or ("nccl" if torch.cuda.is_available() else "gloo"), rank=rank, world_size=world)
@@ -103,13 +104,9 @@ class GradientBuckets:
             self._views.append(views)
         self._pending = [len(b) for b in self.buckets]
         self._work = [None] * len(self.buckets)
+        # the hooks read gradients DURING backward: every weight gradient must be complete when its hook fires.  ops._wgrad
+        # sees the hooks on the parameters and keeps those gradients out of the end-of-pass batched slab sum.
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in params] if (world_size > 1 and overlap) else []
-        if self._hooks and params and params[0].is_cuda:
-            from .. import ops
-
-            # the hooks read gradients DURING backward: every weight gradient must be complete when its hook fires, so the
-            # end-of-pass batched slab sum (ops._flush_wgrads) cannot be used with this schedule
-            ops.set_wgrad_deferred(False)
 
     def _launch(self, bi, grads=None):
         """pack the bucket's gradients into its flat buffer (one multi-tensor copy) and start the all-reduce."""

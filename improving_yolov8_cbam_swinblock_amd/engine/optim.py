@@ -82,7 +82,7 @@ class ModelEMA:
 class FusedSGD:
     """SGD(momentum, nesterov) over the reference's three parameter groups + gradient clipping (+ EMA), fused."""
 
-    def __init__(self, model, lr=0.01, momentum=0.937, decay=5e-4, nesterov=True, max_norm=10.0, ema=None, world_size=1, sgd=True):
+    def __init__(self, model, lr=0.01, momentum=0.937, decay=5e-4, nesterov=True, max_norm=10.0, ema=None, sgd=True):
         self.model = model
         g_bias, g_w, g_norm = param_groups_of(model) if sgd else ([], [], [])
         # group order of the reference's optimizer: [biases] + add_param_group(weights, decay) + add_param_group(norm weights)
@@ -92,7 +92,7 @@ class FusedSGD:
             {"params": g_norm, "lr": lr, "initial_lr": lr, "momentum": momentum, "nesterov": nesterov, "weight_decay": 0.0, "dampening": 0},
         ]
         self.max_norm = float(max_norm) if max_norm else 0.0
-        self.world = int(world_size)
+        self.world = 1  # gradients arrive already averaged over ranks (GradientBuckets.finish); hyper[11] = 1 / world stays 1
         self.ema = ema
         self.sgd = sgd
         self._table = None
@@ -153,8 +153,7 @@ class FusedSGD:
         self.n_grad_chunks = first_chunk_of[self.n_sgd] if self.sgd else len(cmap)
         self._partials = torch.zeros(max(self.n_grad_chunks, 1), dtype=torch.float32, device=dev)
         self._state = torch.zeros(32, dtype=torch.uint8, device=dev)
-        if self.ema is not None and self.ema.updates:
-            self._state.view(torch.int64)[2] = int(self.ema.updates)
+        self._dev_updates = 0  # host mirror of the device-side EMA update counter (_state[2]); see _sync_updates
         self._hyper = torch.zeros(12, dtype=torch.float32, device=dev)
         self._hyper_host = None  # a fresh device array: the next sync_hyper() must fill it
         self._ptrs = [p.data_ptr() for p, *_ in entries]
@@ -176,6 +175,23 @@ class FusedSGD:
         if host != self._hyper_host:
             self._hyper.copy_(torch.tensor(host, dtype=torch.float32))
             self._hyper_host = host
+        self._sync_updates()
+
+    def _sync_updates(self):
+        """the kernel derives the EMA decay from a DEVICE counter; `ema.updates` is the host's view of it.  A caller may set
+        the host value at any time - checkpoint.resume, or the reference's idiom `ema.updates = ckpt["updates"]`
+        (trainer.py:771) - possibly after the tables were built: push it whenever it differs from what the device holds
+        (runs before every step and before every graph replay, outside captured regions)."""
+        if self.ema is not None and self._table is not None and int(self.ema.updates) != self._dev_updates:
+            self._state.view(torch.int64)[2] = int(self.ema.updates)
+            self._dev_updates = int(self.ema.updates)
+
+    def count_updates(self, delta):
+        """bookkeeping of HIP-graph replays (engine.trainer.TrainStep): a replayed step advanced the device counter (+1); a
+        captured, not executed, step did not (-1).  Keeps the host count and the mirror of the device counter together."""
+        if self.ema is not None:
+            self.ema.updates += delta
+            self._dev_updates += delta
 
     # ---- the step --------------------------------------------------------------------------------------------------
     def step(self, grads_of=None):
@@ -217,6 +233,7 @@ class FusedSGD:
         self._keep.clear()
         if self.ema is not None:
             self.ema.updates += 1
+            self._dev_updates += 1
 
     def grad_norm(self):
         """total gradient norm of the last step (before clipping), as clip_grad_norm_ returns it: one device->host read."""

@@ -16,10 +16,12 @@ from .optim import FusedSGD, ModelEMA
 ASYNC_WGRAD = os.environ.get("YMI_WGRAD_STREAM", "1") != "0"
 
 
-def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, ema=None, world_size=1):
+def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, ema=None):
     """reference build_optimizer (trainer.py:788-849, 'SGD' branch :832-833) + optimizer_step's clip (:617): three
-    parameter groups, nesterov momentum, weight decay on the weights only - as the fused HIP step (engine/optim.py)."""
-    return FusedSGD(model, lr=lr, momentum=momentum, decay=decay, nesterov=True, max_norm=10.0, ema=ema, world_size=1)
+    parameter groups, nesterov momentum, weight decay on the weights only - as the fused HIP step (engine/optim.py).
+    The gradients it is handed are already the mean over ranks (GradientBuckets.finish divides once), so the step itself
+    never scales by the world size."""
+    return FusedSGD(model, lr=lr, momentum=momentum, decay=decay, nesterov=True, max_norm=10.0, ema=ema)
 
 
 def synthetic_batch(batch, imgsz, device, seed, boxes_per_image=4):
@@ -95,7 +97,7 @@ class TrainStep:
             if not self.full_graph:  # the gradients the replays rewrite in place
                 self._graph_grads = {p: p.grad for p in self.params if p.grad is not None}
             elif self.ema is not None:
-                self.ema.updates -= 1  # the capture recorded the update without running it
+                self.opt.count_updates(-1)  # the capture recorded the update without running it
         else:
             for k, v in batch.items():
                 if torch.is_tensor(v) and v is not self._static[k]:
@@ -109,7 +111,7 @@ class TrainStep:
         self._graph.replay()
         if self.full_graph:
             if self.ema is not None:
-                self.ema.updates += 1  # the captured step advanced the device counter
+                self.opt.count_updates(+1)  # the captured step advanced the device counter
         else:
             self._reduce_and_update(self._graph_grads)
             self.opt.zero_grad(set_to_none=True)  # drops references only: the graph owns its gradient buffers
@@ -120,7 +122,11 @@ class TrainStep:
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             loss, items = self.model(batch)
             total = loss.sum() * self.world
-        with ops.async_wgrad(ASYNC_WGRAD and not self.use_graph):  # joins the side stream on exit
+        # this step owns its gradients: zero_grad(set_to_none=True) after every update, so AccumulateGrad adopts the tensors
+        # the weight-gradient Functions return and nothing reads them before backward() is over - the condition under which
+        # their slab sums may be batched into one launch at the end of the pass (ops.deferred_wgrad; parameters that do hold a
+        # gradient or a hook - the overlapped DDP schedule - are detected there and reduced at once)
+        with ops.deferred_wgrad(True), ops.async_wgrad(ASYNC_WGRAD and not self.use_graph):  # joins the side stream on exit
             total.backward()
         return items
 

@@ -34,13 +34,19 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x, out=None):
-        x = ops.to_internal(x)
-        if self.add and self.training and ops.join_of(x) is None:
-            ops.mark_join(x, 2)  # consumers of x here: cv1 and the shortcut; their gradient sum forms in cv1's data-gradient epilogue
-        h = self.cv1(x)
+        xi = ops.to_internal(x)
+        # the shortcut rides in cv2's BatchNorm + SiLU kernel when cv1's operand IS the tensor to add.  A width that is not a
+        # multiple of the 16-byte chunk reaches cv1 as a zero-padded copy (more channels than cv2 produces): the add is then a
+        # separate launch on the caller's tensor and autograd forms the gradient sum
+        fused_add = self.add and xi.shape[1] == self.cv2.conv.out_channels
+        if fused_add and self.training and ops.join_of(xi) is None:
+            ops.mark_join(xi, 2)  # consumers of x here: cv1 and the shortcut; their gradient sum forms in cv1's data-gradient epilogue
+        h = self.cv1(xi)
         if self.training:
             ops.mark_sole(h)  # h feeds cv2 only: cv2's data gradient may carry the reduce pass of cv1's BatchNorm backward
-        return self.cv2(h, residual=x if self.add else None, out=out)
+        if fused_add or not self.add:
+            return self.cv2(h, residual=xi if self.add else None, out=out)
+        return ops.add_residual(self.cv2(h), x, out)
 
 
 class C2f(nn.Module):
@@ -59,7 +65,8 @@ class C2f(nn.Module):
         x = ops.to_internal(x)
         buf, slot = None, (lambda j: None)
         dt = x.dtype
-        if self.training and hasattr(self.cv1, "bn") and self.c % ops.chunk_elems(dt) == 0:
+        dense = self.c % ops.chunk_elems(dt) == 0
+        if self.training and hasattr(self.cv1, "bn") and dense:
             # train mode: cv1 and every Bottleneck write straight into their slice of the concat buffer
             n, _, h, w = x.shape
             buf = ops.empty_nhwc(n, (2 + len(self.m)) * self.c, h, w, dt, x.device)
@@ -70,7 +77,10 @@ class C2f(nn.Module):
         for j, m in enumerate(self.m):
             # consumers of a Bottleneck's input: its cv1, its shortcut (if any) and - for j >= 1, where the input is the
             # previous Bottleneck's output - the concat; the right half of t reaches the concat through c2f_split instead
-            if buf is not None:
+            # Marked whenever the Bottleneck consumes `last` itself (a width in whole 16-byte chunks: to_internal is the identity),
+            # with or without the concat buffer - ops.concat is a join-aware consumer either way.  Other widths reach the
+            # Bottleneck as padded copies: autograd sums their gradients and nothing is marked.
+            if dense:
                 ops.mark_join(last, 1 + int(m.add) + int(j >= 1))
             last = m(last, out=slot(2 + j))
             ys.append(last)

@@ -110,8 +110,10 @@ class Detect(nn.Module):
             maps = [ops.to_internal(t) for t in box]
             box = [t[:, : self.reg_max * 4].contiguous(memory_format=torch.channels_last) for t in maps]
             cls = [t[:, self.reg_max * 4 :].contiguous(memory_format=torch.channels_last) for t in maps]
-        if getattr(self, "_stride_host", None) is None or len(self._stride_host) != self.nl:
+        key = (self.stride.data_ptr(), self.stride._version, self.stride.device)  # re-read after `stride` is assigned, edited or moved
+        if getattr(self, "_stride_key", None) != key:
             self._stride_host = [float(s) for s in self.stride]  # one device->host read, not one per call
+            self._stride_key = key
         return ops.detect_decode(box, cls, self._stride_host)
 
     def bias_init(self):

@@ -244,10 +244,10 @@ def _conv_out_hw(h, w, k, s):
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
-def _wgrad(x, dy, cout, cin, k, stride, want_bias):
-    """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None)"""
-    if _deferred["on"] and _in_backward():
-        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias)
+def _wgrad(x, dy, cout, cin, k, stride, want_bias, params=()):
+    """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None).  params: the parameters these gradients belong to."""
+    if _deferred["on"] and _in_backward() and _adoptable(params):
+        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, params[0] if params else None)
     dev = x.device
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
     db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
@@ -256,6 +256,17 @@ def _wgrad(x, dy, cout, cin, k, stride, want_bias):
     ws = workspace(need, dev, "wgrad")
     check(L().ymi_conv2d_bwd_weight(_byref(tx), _byref(ty), cout, cin, k, k, stride, ptr(dw), ptr(db), ptr(ws), ws.numel(), stream_ptr()), "conv2d_bwd_weight")
     return dw, db
+
+
+def _adoptable(params):
+    """True when AccumulateGrad will adopt freshly returned gradient tensors of these parameters as `.grad` WITHOUT reading
+    them during the pass: no gradient accumulated yet, and no hooks that run when the gradient arrives."""
+    for p in params:
+        if p is None:
+            continue
+        if p.grad is not None or getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
 
 
 def _in_backward():
@@ -308,36 +319,69 @@ def join_side_stream():
         _async["keep"].clear()
 
 
-def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias):
+def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias, params=()):
     if not _async["on"]:
-        return _wgrad(x, dy, cout, cin, k, stride, want_bias)
+        return _wgrad(x, dy, cout, cin, k, stride, want_bias, params)
     cur = torch.cuda.current_stream()
     side = _side_stream(x.device)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        out = _wgrad(x, dy, cout, cin, k, stride, want_bias)
+        out = _wgrad(x, dy, cout, cin, k, stride, want_bias, params)
     _async["keep"].append((x, dy))
     _async["pending"] = True
     return out
 
 
 # ---- slab sums of ALL weight gradients of a backward pass in one launch ---------------------------------------------
-# Inside a backward pass every weight-gradient GEMM leaves its split-K slabs un-summed and registers a record; a callback
-# the autograd engine runs when the pass ends (before backward() returns) sums them all with ONE launch
-# (ymi_wgrad_reduce_batch).  Until then the returned dW tensors hold no data: nothing reads a gradient before the pass is
-# over, EXCEPT post-accumulate-grad hooks (the overlapped DDP schedule) - engine/ddp.py switches the deferral off there.
-_deferred = {"on": True, "records": [], "keep": [], "queued": False, "table": None}
+# Inside `deferred_wgrad()` every weight-gradient GEMM of a backward pass leaves its split-K slabs un-summed and registers a
+# record; a callback the autograd engine runs when the pass ends (before backward() returns) sums them all with ONE launch
+# (ymi_wgrad_reduce_batch).  Until then the returned dW tensors hold no data.  That is only safe when NOTHING reads a weight
+# gradient before the pass is over:
+#   * AccumulateGrad must adopt the tensor as `.grad` (p.grad is None when the pass starts).  With gradient accumulation
+#     - a second backward() before zero_grad, as the reference trainer does for nbs / batch > 1 (trainer.py:305,397) -
+#     AccumulateGrad runs `p.grad += dw` DURING the pass and would read the unfilled tensor;
+#   * no post-accumulate-grad hooks (the overlapped DDP schedule of engine/ddp.py) and no tensor hooks on parameters.
+# So the deferral is OPT-IN: engine.trainer.TrainStep, which zeroes gradients with set_to_none=True after every step and
+# knows its DDP schedule, enables it around its backward.  Everywhere else (plain autograd use of the modules, gradient
+# accumulation, hooks) each weight gradient is complete when its Function returns.
+_deferred = {"on": False, "records": [], "keep": [], "owners": [], "task": None, "table": None}
+
+
+class deferred_wgrad:
+    """context manager: batch the split-K slab sums of every weight gradient of the backward passes run inside it.  The
+    caller guarantees the conditions above; parameters that already hold a gradient are detected by _wgrad and not deferred."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = _deferred["on"]
+        _deferred["on"] = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _deferred["on"] = self.prev
+        return False
 
 
 def set_wgrad_deferred(flag):
+    """process-wide switch (tests / tools); prefer the `deferred_wgrad` context manager."""
     _deferred["on"] = bool(flag)
 
 
 def _flush_wgrads():
-    recs, keep = _deferred["records"], _deferred["keep"]
-    _deferred["records"], _deferred["keep"], _deferred["queued"] = [], [], False
+    recs, keep, owners = _deferred["records"], _deferred["keep"], _deferred["owners"]
+    _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["task"] = [], [], [], None
     if not recs:
         return
+    # Every node of the pass has run: a parameter's AccumulateGrad has either ADOPTED the returned tensor (p.grad is that
+    # memory - the usual case, and the reason the tensor must not be referenced from here: a second reference makes
+    # AccumulateGrad clone it) or, if the gradient layout contract failed, stored a clone of the still unfilled tensor and
+    # dropped the original.  In the second case the sum is written straight into p.grad instead of into freed memory.
+    for rec, owner in zip(recs, owners):
+        g = owner.grad if owner is not None else None
+        if g is not None and g.data_ptr() != rec.dw and g.dtype == torch.float32 and g.is_contiguous():
+            rec.dw = g.data_ptr()
     dev = keep[0][0].device
     n = len(recs)
     tab = _deferred["table"]
@@ -353,8 +397,16 @@ def _flush_wgrads():
     del keep
 
 
-def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias):
-    """as _wgrad, with the slab sum left to the end of the backward pass.  The slabs stay alive in _deferred['keep']."""
+def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
+    """as _wgrad, with the slab sum left to the end of the backward pass.  Slabs and operands stay alive in _deferred['keep']
+    until the flush has been enqueued; the gradient tensor itself is owned by autograd (see _flush_wgrads).  owner: the weight."""
+    task = torch._C._current_graph_task_id()
+    if _deferred["task"] != task:
+        # first deferred gradient of this pass.  Records of an earlier pass whose end-of-pass callback never ran (the engine
+        # drops callbacks when a backward raises) are stale: their gradient tensors are gone - discard them.
+        _deferred["records"], _deferred["keep"], _deferred["owners"] = [], [], []
+        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+        _deferred["task"] = task
     dev = x.device
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
     db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
@@ -366,9 +418,7 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias):
           "conv2d_bwd_weight")
     _deferred["records"].append(rec)
     _deferred["keep"].append((ws, x, dy))
-    if not _deferred["queued"]:
-        torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
-        _deferred["queued"] = True
+    _deferred["owners"].append(owner)
     return dw, db
 
 
@@ -658,7 +708,7 @@ class _ConvBnAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _dgrad_joined(join, draw, weight, k, stride, x.shape, dtype, prod_in)
-        dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False)
+        dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False, (weight,))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None, None
 
 
@@ -667,6 +717,10 @@ def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
     Tensors marked with mark_join() (several consumers) have their gradient sums formed in the data-gradient epilogue."""
     if bn.momentum is None:
         raise RuntimeError("BatchNorm with cumulative moving average (momentum=None) is not supported")
+    if torch.is_grad_enabled() and weight.shape[0] % chunk_elems(x.dtype) != 0 and (x.requires_grad or weight.requires_grad):
+        # the backward kernels (BatchNorm backward, data / weight gradient GEMMs) read the output gradient in 16-byte chunks
+        raise NotImplementedError(f"training a Conv with {weight.shape[0]} output channels in {x.dtype}: the backward kernels need channel counts in "
+                                  f"whole 16-byte chunks (multiples of {chunk_elems(x.dtype)}); every standard YOLOv8 width is - use float32 for this width")
     grad = torch.is_grad_enabled() and _bn_fuse["on"]
     prod_out = BnProducer() if (grad and residual is None) else None
     out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual, slot,
@@ -737,6 +791,7 @@ class _ConvAffineAct(torch.autograd.Function):
         else:
             ctx.unsupported = None
         ctx.save_for_backward(x, weight)
+        ctx.bias_param = bias if (bias is not None and bias.requires_grad) else None  # (a leaf parameter: no cycle)
         ctx.cfg = (stride, i, bias is not None, residual is not None, cout_pad)
         ctx.joins = (join, res_join)
         ctx.prod_in = prod_in
@@ -774,7 +829,7 @@ class _ConvAffineAct(torch.autograd.Function):
                 if adds is None:
                     join.deposit(dx)
                     dx = None
-        dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias)
+        dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias, (weight, ctx.bias_param))
         dw = dw.view(weight.shape)
         return dx, dw, None, db, None, None, dres, None, None, None, None
 
@@ -817,6 +872,7 @@ class _SwinMlp(torch.autograd.Function):
             "swin_mlp_fwd",
         )
         ctx.save_for_backward(u, w1, w2, pre, post)
+        ctx.biases = (b1, b2)
         ctx.cfg = (b1 is not None, b2 is not None, residual is not None)
         ctx.joins = (join, res_join)
         return out
@@ -850,8 +906,8 @@ class _SwinMlp(torch.autograd.Function):
             if adds is None:
                 join.deposit(du)
                 du = None
-        dw2, db2 = _wgrad_maybe_async(post, dout, w2.shape[0], hidden, 1, 1, has_b2)
-        dw1, db1 = _wgrad_maybe_async(u, dpre, hidden, c, 1, 1, has_b1)
+        dw2, db2 = _wgrad_maybe_async(post, dout, w2.shape[0], hidden, 1, 1, has_b2, (w2, ctx.biases[1]))
+        dw1, db1 = _wgrad_maybe_async(u, dpre, hidden, c, 1, 1, has_b1, (w1, ctx.biases[0]))
         return du, dw1.view(w1.shape), db1, dw2.view(w2.shape), db2, dres, None, None
 
 
@@ -884,6 +940,32 @@ class _Act(torch.autograd.Function):
 
 def gelu(pre):
     return _Act.apply(pre, ACT_GELU)
+
+
+class _AddResidual(torch.autograd.Function):
+    """y + r as its own launches (Bottleneck shortcut, block.py:488, for widths whose shortcut cannot ride in the BatchNorm + SiLU
+    kernel); both gradients are the incoming one."""
+
+    @staticmethod
+    def forward(ctx, y, r, slot=None):
+        n, c, h, w = y.shape
+        out = slot.view(n, c, h, w, y.dtype) if slot is not None else empty_nhwc(n, c, h, w, y.dtype, y.device)
+        check(L().ymi_copy(_byref(as_ymi(y)), _byref(as_ymi(out)), stream_ptr()), "copy")
+        check(L().ymi_add_inplace(_byref(as_ymi(r)), _byref(as_ymi(out)), stream_ptr()), "add_inplace")
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g, None
+
+
+def add_residual(y, r, slot=None):
+    """y: internal tensor; r: any [N, C, H, W] cuda tensor of the same channel count (brought to y's dtype and NHWC memory)."""
+    if r.dtype != y.dtype or not is_nhwc(r):
+        buf = empty_nhwc(*r.shape, y.dtype, r.device)
+        buf.copy_(r)
+        r = buf
+    return _AddResidual.apply(y, r, slot)
 
 
 # ------------------------------------------------------------------------ concat / upsample

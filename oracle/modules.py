@@ -13,6 +13,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .quant import st, stf  # storage-precision mode (identity unless oracle.quant.storage(dtype) is active)
+
 
 def autopad(k, p=None, d=1):
     """'same' padding for kernel k / dilation d.  nn/modules/conv.py:28-34."""
@@ -57,12 +59,17 @@ class Conv(nn.Module):
         self.bn = nn.BatchNorm2d(c2)
         self.has_act = act is True
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual: Bottleneck's shortcut (block.py:488), added here so that storage-precision mode rounds the sum once,
+        as the product's fused BatchNorm + SiLU + add kernel does; plain float32 arithmetic is unchanged by it."""
         c = self.conv
         y = F.conv2d(x, c.weight, c.bias, c.stride, c.padding, c.dilation, c.groups)
         if hasattr(self, "bn"):  # conv.py:79 ; after fuse() (tasks.py:219-225) the bn is gone: conv.py:81-91
-            y = batchnorm2d(y, self.bn, self.training)
-        return silu(y) if self.has_act else y
+            y = batchnorm2d(st(y), self.bn, self.training)  # the raw convolution output is a stored tensor (BatchNorm backward reads it)
+        y = silu(y) if self.has_act else y
+        if residual is not None:
+            y = residual + y
+        return st(y)
 
 
 def fuse_conv_and_bn(conv, bn):
@@ -99,8 +106,7 @@ class Bottleneck(nn.Module):
         self.add = shortcut and c1 == c2
 
     def forward(self, x):
-        y = self.cv2(self.cv1(x))
-        return x + y if self.add else y
+        return self.cv2(self.cv1(x), residual=x if self.add else None)
 
 
 class C2f(nn.Module):
@@ -121,17 +127,23 @@ class C2f(nn.Module):
         return self.cv2(torch.cat(ys, 1))
 
 
+def first_max(x, dim):
+    """max over `dim` whose gradient goes to the FIRST maximal element in index order - the rule of every max the
+    reference uses on this path (nn.MaxPool2d, nn.AdaptiveMaxPool2d, torch.max(dim): ATen keeps the running maximum and
+    replaces it only by a strictly greater value).  `amax` / `torch.maximum` would split the gradient between tied
+    elements instead.  Pinned by the reference-generated fixtures `*_ties` (tests/golden/make_golden.py ties)."""
+    idx = x.argmax(dim=dim, keepdim=True)  # "the indices of the first maximal value are returned"
+    return x.gather(dim, idx).squeeze(dim)
+
+
 def maxpool_same(x, k):
-    """MaxPool2d(k, stride 1, pad k//2) with -inf padding, as a sliding-window max.  block.py:220."""
+    """MaxPool2d(k, stride 1, pad k//2) with -inf padding (block.py:220): the k*k window positions in the order ATen scans
+    them (rows, then columns), first maximum wins."""
     p = k // 2
     xp = F.pad(x, (p, p, p, p), value=float("-inf"))
     H, W = x.shape[-2:]
-    out = None
-    for dy in range(k):
-        for dx in range(k):
-            v = xp[..., dy : dy + H, dx : dx + W]
-            out = v if out is None else torch.maximum(out, v)
-    return out
+    cols = torch.stack([xp[..., dy : dy + H, dx : dx + W] for dy in range(k) for dx in range(k)], dim=-1)
+    return first_max(cols, -1)
 
 
 class SPPF(nn.Module):
@@ -179,7 +191,7 @@ class ChannelAttention(nn.Module):
         w1 = self.shared_MLP[0].weight.flatten(1)  # [hidden, C]
         w2 = self.shared_MLP[2].weight.flatten(1)  # [C, hidden]
         avg = x.mean(dim=(2, 3))  # [B, C]
-        mx = x.amax(dim=(2, 3))
+        mx = first_max(x.flatten(2), -1)  # nn.AdaptiveMaxPool2d(1), cbam.py:9,36: first maximum in row-major pixel order
         z = torch.relu(avg @ w1.t()) @ w2.t() + torch.relu(mx @ w1.t()) @ w2.t()
         return torch.sigmoid(z)[:, :, None, None]
 
@@ -193,7 +205,7 @@ class SpatialAttention(nn.Module):
         self.conv = nn.Conv2d(2, 1, kernel_size, padding=3 if kernel_size == 7 else 1, bias=False)
 
     def forward(self, x):
-        s = torch.cat((x.mean(dim=1, keepdim=True), x.amax(dim=1, keepdim=True)), 1)
+        s = torch.cat((x.mean(dim=1, keepdim=True), first_max(x, 1).unsqueeze(1)), 1)  # torch.max(x, dim=1), cbam.py:50: first maximal channel
         return torch.sigmoid(F.conv2d(s, self.conv.weight, None, 1, self.conv.padding))
 
 
@@ -207,7 +219,7 @@ class CBAM(nn.Module):
 
     def forward(self, x):
         x = x * self.ca(x)
-        return x * self.sa(x)
+        return st(x * self.sa(x))  # (the product keeps x * ca in registers: only the result is a stored tensor)
 
 
 def window_partition(x, ws):
@@ -252,13 +264,13 @@ def multihead_self_attention(t, mha):
     Bn, L, C = t.shape
     h = mha.num_heads
     hd = C // h
-    qkv = t @ mha.in_proj_weight.t() + mha.in_proj_bias
+    qkv = st(t @ mha.in_proj_weight.t() + mha.in_proj_bias)
     q, k, v = qkv.split(C, dim=-1)
     q = q.view(Bn, L, h, hd).transpose(1, 2) * (1.0 / math.sqrt(hd))
     k = k.view(Bn, L, h, hd).transpose(1, 2)
     v = v.view(Bn, L, h, hd).transpose(1, 2)
     p = torch.softmax(q @ k.transpose(-1, -2), dim=-1)
-    o = (p @ v).transpose(1, 2).reshape(Bn, L, C)
+    o = st((stf(p) @ v).transpose(1, 2).reshape(Bn, L, C))
     return o @ mha.out_proj.weight.t() + mha.out_proj.bias
 
 
@@ -286,11 +298,11 @@ class SwinBlock(nn.Module):
         x = F.pad(x, (0, pw, 0, ph))
         Hp, Wp = H + ph, W + pw
         t = window_partition(x.permute(0, 2, 3, 1).contiguous(), ws)
-        t = layernorm(t, self.norm1)
-        t = t + multihead_self_attention(t, self.attn)
-        u = layernorm(t, self.norm2)
-        u = gelu_erf(u @ self.mlp[0].weight.t() + self.mlp[0].bias) @ self.mlp[2].weight.t() + self.mlp[2].bias
-        t = t + u
+        t = st(layernorm(t, self.norm1))
+        t = st(t + multihead_self_attention(t, self.attn))
+        u = st(layernorm(t, self.norm2))
+        h = st(gelu_erf(st(u @ self.mlp[0].weight.t() + self.mlp[0].bias)))
+        t = st(t + (h @ self.mlp[2].weight.t() + self.mlp[2].bias))
         x = window_reverse(t, ws, Hp, Wp).permute(0, 3, 1, 2)
         return x[:, :, :H, :W]
 
@@ -357,7 +369,7 @@ class Detect(nn.Module):
         self.dfl = DFL(self.reg_max)
 
     def forward(self, x):
-        x = [torch.cat((self.cv2[i](x[i]), self.cv3[i](x[i])), 1) for i in range(self.nl)]  # head.py:71-72
+        x = [st(torch.cat((self.cv2[i](x[i]), self.cv3[i](x[i])), 1)) for i in range(self.nl)]  # head.py:71-72 (the biased 1x1 outputs are stored tensors)
         if self.training:
             return x
         return self._inference(x), x

@@ -357,8 +357,52 @@ def opt_step_fixture():
     (OUT / "opt_step_tiny.json").write_text(json.dumps(meta))
 
 
+def tie_fixtures():
+    """arg-max routing on TIED values, produced by the reference's own modules: inputs quantised to 16 levels,
+    so nearly every max has several maximal elements.  nn.MaxPool2d of the reference's SPPF (block.py:220,225), and the
+    reference CBAM (AdaptiveMaxPool2d(1) cbam.py:9, torch.max(dim=1) cbam.py:50) once with random weights (ties in the
+    per-channel spatial max) and once with a zero second MLP layer (ca = 0.5 for every channel, so the per-pixel channel
+    max of x * ca is tied too).  Output gradients are small dyadic numbers: every gradient sum of the pool fixtures is
+    exact in float32, so they are compared bit for bit.  Own RNG stream."""
+    torch.set_num_threads(4)
+    g = torch.Generator().manual_seed(4321)
+    cbam = load_leaf("ref_cbam", "ultralytics/nn/modules/cbam.py")
+    import_reference_package()
+    from ultralytics.nn.modules.block import SPPF
+
+    def levels(shape, n=16, step=0.25):
+        return (torch.randint(0, n, shape, generator=g).float() - n // 2) * step
+
+    for k, (H, W) in ((5, (11, 13)), (7, (10, 9))):
+        pool = SPPF(16, 16, k).m  # the reference's nn.MaxPool2d(k, 1, k // 2)
+        x = levels((2, 8, H, W)).requires_grad_(True)
+        ys = [x]
+        ys.extend(pool(ys[-1]) for _ in range(3))  # block.py:224-225
+        cat = torch.cat(ys, 1)
+        gy = levels(cat.shape, 16, 0.125)
+        (gx,) = torch.autograd.grad(cat, x, gy)
+        save(f"pool_ties_k{k}", x=x.detach().numpy(), y=cat.detach().numpy(), gy=gy.numpy(), **{"g.x": gx.numpy()}, k=np.array(k))
+
+    for name, flat in (("cbam_ties_c32", False), ("cbam_ties_flatca_c32", True)):
+        m = cbam.CBAM()
+        x = levels((2, 32, 12, 12))
+        m(x)  # creates the lazy MLP
+        randomize(m, g)
+        if flat:
+            with torch.no_grad():
+                m.ca.shared_MLP[2].weight.zero_()
+        x.requires_grad_(True)
+        y = m(x)
+        gy = levels(y.shape, 16, 0.125)
+        grads = torch.autograd.grad(y, [x] + list(m.parameters()), gy)
+        names = ["x"] + [n for n, _ in m.named_parameters()]
+        save(name, x=x.detach().numpy(), y=y.detach().numpy(), gy=gy.numpy(), **{"g." + n: t.numpy() for n, t in zip(names, grads)}, **sd_np(m))
+
+
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "swin_large":
+    if len(sys.argv) > 1 and sys.argv[1] == "ties":
+        tie_fixtures()
+    elif len(sys.argv) > 1 and sys.argv[1] == "swin_large":
         swin_large_fixtures()
     elif len(sys.argv) > 1 and sys.argv[1] == "opt_step":
         opt_step_fixture()
@@ -366,3 +410,4 @@ if __name__ == "__main__":
         main()
         swin_large_fixtures()
         opt_step_fixture()
+        tie_fixtures()

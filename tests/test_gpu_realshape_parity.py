@@ -36,8 +36,9 @@ def _threads():
     torch.set_num_threads(min(16, len(os.sched_getaffinity(0))))
 
 
-def _pair(cfg, seed=0):
+def _pair(cfg, seed=0, round_weights=False):
     from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+    from oracle import quant
     from oracle.tasks import DetectionModel as OracleModel
 
     torch.manual_seed(seed)
@@ -49,16 +50,27 @@ def _pair(cfg, seed=0):
             if isinstance(m, (torch.nn.BatchNorm2d, torch.nn.LayerNorm)):
                 m.weight.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=g))
                 m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+    if round_weights:  # bf16-representable conv / linear weights on both sides (the product packs them to bf16)
+        quant.round_weights_(oracle)
     model = DetectionModel(cfg, ch=3, nc=1)
     model.load_state_dict(oracle.state_dict(), strict=True)
     return oracle, model.to(dev()).train()
 
 
-def _oracle_run(oracle, batch):
-    """oracle forward + loss + backward; records every top-level layer's input(s), output(s) and output gradient(s)."""
+def _oracle_run(oracle, batch, storage=None):
+    """oracle forward + loss + backward; records every top-level layer's input(s), output(s) and output gradient(s).
+    storage: run the oracle in storage-precision mode (oracle/quant.py) - the quantisation-matched reference of the bf16 path."""
+    import contextlib
+
+    from oracle import quant
     from oracle.loss import v8DetectionLoss as OracleLoss
 
     _threads()
+    with (quant.storage(storage) if storage is not None else contextlib.nullcontext()):
+        return _oracle_run_inner(oracle, batch, OracleLoss)
+
+
+def _oracle_run_inner(oracle, batch, OracleLoss):
     rec = {}
 
     def hook(mod, inp, out):
@@ -100,8 +112,17 @@ def _noise_floor(name, ref_grads):
     return name.endswith("mlp.2.bias")
 
 
-def _teacher_forced(oracle, model, rec, dtype, tol_fwd, tol_grad, loose=None):
+def _teacher_forced(oracle, model, rec, dtype, tol_fwd, tol_grad, loose=None, storage=None):
     """every top-level layer alone, on the oracle's input and output gradient.  loose: {layer type: bound} overrides."""
+    import contextlib
+
+    from oracle import quant
+
+    with (quant.storage(storage) if storage is not None else contextlib.nullcontext()):
+        return _teacher_forced_inner(oracle, model, rec, dtype, tol_fwd, tol_grad, loose)
+
+
+def _teacher_forced_inner(oracle, model, rec, dtype, tol_fwd, tol_grad, loose):
     worst = []
     for om, gm in zip(oracle.model, model.model):
         r = rec[om.i]
@@ -161,8 +182,9 @@ def test_config3_yolov8s_bs4_640_vs_oracle(dtype):
         # layers behind the last arg-max decision of the backward chain (SPPF 12 -> head): plain float32 agreement
         tail = [(n, e) for n, e in errs if int(n.split(".")[1]) >= 12]
         assert all(e <= 1e-3 for _, e in tail), [t for t in tail if t[1] > 1e-3]
-        # layers 0-11: bounded by the routing discontinuity described in the module docstring
-        assert all(e <= 5e-2 for _, e in errs), [t for t in errs if t[1] > 5e-2]
+        # layers 0-11: bounded by the routing discontinuity described in the module docstring (observed 8e-3: two flipped
+        # near-ties of 409,600 first-pool windows; tools/grad_diag.py)
+        assert all(e <= 2e-2 for _, e in errs), [t for t in errs if t[1] > 2e-2]
         rows = _teacher_forced(oracle, model, rec, dtype, 1e-4, 1e-4)   # same decisions on both sides: float32 noise only
     else:
         assert lrel <= 2e-2, (loss, ref_loss)                # bf16: loss within 2e-2 relative
@@ -215,4 +237,29 @@ def test_config5_yolov8m_swin384_bs2_640_vs_oracle(dtype):
         rows = _teacher_forced(oracle, model, rec, dtype, 2e-2, 5e-2, loose={"SPPF": (2e-2, 0.35), "CBAM": (2e-2, 0.1)})
     _print_worst(f"cfg5 {dtype} teacher-forced", rows)
     bad = [(w, e, t) for w, e, t in rows if not e <= t]
+    assert not bad, bad
+
+
+@pytest.mark.parametrize("cfg,bs,seed", [("yolov8s.yaml", 4, 1), ("yolov8m-cbam-swin384.yaml", 2, 3)], ids=["cfg3", "cfg5"])
+def test_bf16_layers_vs_quantisation_matched_oracle(cfg, bs, seed):
+    """the bf16 step's kernels at the real shapes of configs 3 and 5 (640x640), layer by layer, against the oracle in
+    storage-precision mode on identical bf16-valued weights, inputs and output gradients: what remains is
+    accumulation order and values that round the other way, so the bounds are 4e-3 (outputs) / 1e-2 (gradients) relative L2
+    instead of the 2e-2 .. 0.35 a float32 oracle needs - a mis-routed window or a wrong row of a ragged tile does not fit.
+    Measured (MI355X): Conv 7e-5, Detect 3e-4, SwinBlock 4e-4, CBAM 2e-5 on outputs.  Two layer kinds get their own bounds:
+    * C2f (8e-3 / 2e-2): a value that rounds the other way is a full-ulp error for the next convolution, so along a chain
+      of stored tensors the difference grows towards the unmatched rounding level - tools/c2f_matched_diag.py prints
+      1e-5, 1.5e-4, 4e-4, 1.4e-3, 1.7e-3, 2.6e-3 along the six blocks of a C2f with two Bottlenecks (5.6e-3 with four);
+    * SPPF gradients (3e-2): such a value in front of the pool cascade re-routes the gradient of every window whose maximum
+      it was (arg-max is discontinuous).  With identical values both sides take the same decisions, ties included
+      (tests/test_gpu_bf16_matched.py checks that rule bit for bit)."""
+    from improving_yolov8_cbam_swinblock_amd.engine.trainer import synthetic_batch
+
+    oracle, model = _pair(cfg, round_weights=True)
+    cpu = synthetic_batch(bs, 640, torch.device("cpu"), seed)
+    cpu["img"] = cpu["img"].bfloat16().float()
+    _, _, _, rec = _oracle_run(oracle, cpu, storage=torch.bfloat16)
+    rows = _teacher_forced(oracle, model, rec, torch.bfloat16, 4e-3, 1e-2, loose={"C2f": (8e-3, 2e-2), "SPPF": (4e-3, 3e-2)}, storage=torch.bfloat16)
+    _print_worst(f"{cfg} bf16 vs matched oracle", rows, n=14)
+    bad = [(w, e, tol) for w, e, tol in rows if not e <= tol]
     assert not bad, bad
