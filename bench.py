@@ -149,9 +149,10 @@ def kernel_rev():
     return h.hexdigest()[:12]
 
 
-def traffic_record(family):
+def traffic_record(family, workload):
     """HBM bytes per launch from the latest committed PMC passes (tools/pmc_traffic.py) IF they were taken on the
-    kernels this run executes (same source hash); otherwise None: hardware counters cannot be read from inside the run."""
+    kernels this run executes (same source hash) AND on this workload (model, batch, image size; files without a
+    "workload" entry are the default configuration's); otherwise None: hardware counters cannot be read from inside the run."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -159,7 +160,7 @@ def traffic_record(family):
             try:
                 with open(os.path.join(pdir, name)) as fh:
                     d = json.load(fh)
-                if d.get("kernel_rev") == kernel_rev():
+                if d.get("kernel_rev") == kernel_rev() and d.get("workload", "yolov8s.yaml bs32 640") == workload:
                     best = (d["families"][family]["hbm_bytes_per_launch"], name)
             except (OSError, KeyError, ValueError):
                 continue
@@ -280,7 +281,7 @@ def main():
         fam = 0 if ms[0] >= ms[1] else 1
         names = ["igemm_kernel (implicit-GEMM conv fwd / dgrad / token GEMM)", "wgrad_kernel (weight-gradient split-K GEMM)"]
         ach = fl[fam] / (ms[fam] * 1e-3) / 1e12 if ms[fam] > 0 else 0.0
-        tr = traffic_record(["igemm", "wgrad"][fam])
+        tr = traffic_record(["igemm", "wgrad"][fam], f"{args.model} bs{args.batch} {args.imgsz}")
         roof = {
             "bound": "mfma",
             "kernel": names[fam],
@@ -293,7 +294,7 @@ def main():
             # this source revision
             "traffic": tr[0] if tr else None,
             "traffic_source": (f"profiles/{tr[1]} (HBM bytes per launch, 2*FETCH_SIZE + WRITE_SIZE KiB, kernel_rev {kernel_rev()})" if tr
-                               else f"no PMC pass committed for kernel_rev {kernel_rev()}"),
+                               else f"no PMC pass committed for kernel_rev {kernel_rev()} on this workload"),
             "algorithmic_bytes_per_launch": round(byt[fam] / max(cnt[fam], 1)),
             # every launch against ITS OWN roofline, max(flop / 2.5 PF, algorithmic bytes / 8 TB/s): the 1x1 and
             # narrow convs of this model are HBM-bound, so the family's MFMA fraction alone understates them
