@@ -72,8 +72,6 @@ _SIGNATURES = {
     "ymi_bn_act_bwd": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_data": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
     "ymi_conv2d_bwd_data_add": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp]),
-    "ymi_conv2d_bwd_data_bn": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _vp, _c_i64, ctypes.POINTER(ctypes.c_int64), _TP, _vp]),
-    "ymi_bn_act_bwd_from_partials": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _vp, _c_i64, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_swin_mlp_fwd": (_c_i32, [_TP, _vp, _vp, _c_i64, _vp, _vp, _TP, _TP, _TP, _TP, _vp]),
     "ymi_swin_mlp_bwd_data": (_c_i32, [_TP, _vp, _TP, _TP, _vp, _TP, _TP, _TP, _vp]),
     "ymi_conv2d_bwd_weight": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp]),
@@ -111,7 +109,7 @@ OPT_MAX_GRADS = 448  # YMI_OPT_MAX_GRADS
 
 class WgradPending(ctypes.Structure):
     _fields_ = [("slab", _vp), ("dw", _vp), ("elems", _c_i64), ("splits", _c_i32), ("ng", _c_i32), ("cin", _c_i32), ("cout_real", _c_i32),
-                ("cin_real", _c_i32), ("ntaps", _c_i32), ("lanes", _c_i32), ("first_block", _c_i32), ("blocks", _c_i32), ("_pad", _c_i32)]
+                ("cin_real", _c_i32), ("ntaps", _c_i32), ("lanes", _c_i32), ("first_block", _c_i32), ("blocks", _c_i32), ("slab_bf16", _c_i32)]
 
 
 class OptEntry(ctypes.Structure):

@@ -79,18 +79,6 @@ struct IgemmArgs {
     const void* mul;   // optional multiplier: y = value * act'(mul) with mul_act's derivative (GELU backward inside fc2's data gradient)
     int64_t ldy2, ldmul;
     int act2, mul_act;
-    // BatchNorm-backward mode of a data-gradient launch whose output is the gradient dy of a Conv-BN-act producer: the epilogue
-    // stores u = dy * act'(z^) instead of dy (z^ = BN(raw) of the PRODUCER, recomputed from its raw conv output and saved
-    // statistics) and per-workgroup partial sums of u and u * x^ - the reduce pass of that layer's BN backward, without its read
-    // of dy and without its launch.  bn_partials[(mb * 2 + which) * Cout + ch], as the forward statistics.
-    const void* bn_raw;
-    const float* bn_gamma;
-    const float* bn_beta;
-    const float* bn_mean;
-    const float* bn_inv;
-    float* bn_partials;
-    int64_t ldbn;
-    int bn_act;
     const float* scale;
     const float* bias;
     float* partials;
@@ -128,13 +116,6 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
         static_for<I + 1, N>(f);
     }
 }
-
-// compile-time knob.  0 (default): a step's pieces are issued back to back right after the barrier.  1: spread between
-// the MFMAs of the step - measured 1.1x (data gradient) to 2x (forward) SLOWER (profiles/r02_conv_bench_interleave.txt):
-// with one step of prefetch the pieces need the whole step to land, and issuing them late exposes that latency.
-#ifndef YMI_PIECE_INTERLEAVE
-#define YMI_PIECE_INTERLEAVE 0
-#endif
 
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -222,59 +203,6 @@ template <> struct Mma<bf16_t> {
                 for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
         }
     }
-
-    // The same K step with the NP LDS-DMA pieces of a LATER step spread between its MFMAs: piece(p) is called after MFMA
-    // (2p+1)*NM/(2NP) of the NM in the step.  Issued back to back at the head of the step (next to the 16 fragment reads)
-    // a piece holds its wave for 100-185 cycles, among MFMAs for 25-60 (MI355X_MICROARCH.md, LDS-DMA piece issue cost).
-    template <int TM, int TN, int CPR, int NP, class F>
-    static __device__ __forceinline__ void step_issue(const char* As, const char* Bs, int a_row0, int b_row0, int lane, f32x4 (&acc)[TN][TM], F&& piece) {
-        constexpr int ROWB = CPR * 16;
-        const int l15 = lane & 15, l4 = lane >> 4;
-        const int sw = CPR == 4 ? ((-(l15 >> 2)) & 3) : ((l15 >> 1) & 7);
-        constexpr int KS = CPR / 4;
-        constexpr int NM = KS * TN * TM;
-        static_assert(NM >= NP, "at least one MFMA per piece");
-        bf16x8 wf[KS][TN], xf[KS][TM];
-        const uint32_t bbase = (uint32_t)(uintptr_t)(lptr_t)(Bs + (b_row0 + l15) * ROWB);
-        const uint32_t abase = (uint32_t)(uintptr_t)(lptr_t)(As + (a_row0 + l15) * ROWB);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const uint32_t coff = (uint32_t)(((4 * ks + l4) ^ sw) << 4);
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[ks][tn]) : "v"(bbase + coff), "n"(tn * 16 * ROWB));
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm)
-                asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(xf[ks][tm]) : "v"(abase + coff), "n"(tm * 16 * ROWB));
-        }
-        static_for<0, KS>([&](auto ksc) {
-            constexpr int ks = decltype(ksc)::value;
-            __builtin_amdgcn_sched_barrier(0);
-            if constexpr (ks + 1 < KS) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TN + TM) : "memory");
-            else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int tn = 0; tn < TN; ++tn) asm volatile("" : "+v"(wf[ks][tn]));
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) asm volatile("" : "+v"(xf[ks][tm]));
-            static_for<0, TN>([&](auto tnc) {
-                constexpr int tn = decltype(tnc)::value;
-                static_for<0, TM>([&](auto tmc) {
-                    constexpr int tm = decltype(tmc)::value;
-                    constexpr int q = (ks * TN + tn) * TM + tm;
-                    acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
-                    static_for<0, NP>([&](auto pc) {
-                        constexpr int pp = decltype(pc)::value;
-                        if constexpr (q == ((2 * pp + 1) * NM) / (2 * NP)) {
-                            __builtin_amdgcn_sched_barrier(0);
-                            piece(pc);
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                    });
-                });
-            });
-            __builtin_amdgcn_sched_barrier(0);
-        });
-    }
 };
 template <> struct Mma<float> {
     // one K step = 16 floats per row = four 16x16x4 f32 MFMAs per tile pair (64-byte rows only)
@@ -317,9 +245,9 @@ __device__ __forceinline__ float row16_sum(float v) {
 // stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines (per-lane 8-byte stores
 // to 16 different rows cost 2-3x the time of the same bytes stored this way).  STATS: raw output + deterministic
 // per-block BatchNorm partial sums; otherwise scale / bias / activation / up to two addends.
-template <typename T, int BM, int BN, int WM, int WN, bool STATS, int NT, bool BNB = false>
+template <typename T, int BM, int BN, int WM, int WN, bool STATS, int NT>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[BN / WN / 16][BM / WM / 16], char* smem, int m0, int n0, int mb, int wm,
-                                               int wn, int lane, int tid_all, bool consumer
+                                               int wn, int lane, int tid_all
 #ifdef YMI_STAMPS
                                                , bool stamp_on = false, int wave_all = 0, unsigned long long stamp_mt0 = 0
 #endif
@@ -360,7 +288,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     const int act = STATS ? (int)YMI_ACT_NONE : a.act;
     const bool res1 = !STATS && rg && a.vec_store && (a.Cout & 3) == 0 && act == YMI_ACT_NONE;  // addends joined per tile (f32, before the one rounding)
     const bool res2nd = !STATS && rg && !res1;                              // ... or after the activation, from the LDS image
-    if (consumer) {
+    {
     int64_t rpx[TM];
     if (res1) {
 #pragma unroll
@@ -429,7 +357,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
             }
         }
     }
-    }  // consumer
+    }
     YMI_STAMP_MARK(3);  // accumulators converted and dropped into the LDS image
     __syncthreads();
     YMI_STAMP_MARK(4);  // past the barrier
@@ -448,84 +376,6 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
         constexpr int EPC = 16 / ES;       // elements per chunk
         const T* mulp = STATS ? nullptr : reinterpret_cast<const T*>(a.mul);
         const bool post = act != YMI_ACT_NONE || res2nd || mulp;  // (workgroup-uniform) something left to do on the stored values
-        // (BNB: the BatchNorm-backward mode is its own instantiation - compiled into every data-gradient kernel its extra kernel
-        // arguments and registers cost the ordinary path 4 % through scalar-register spills)
-        const T* bnraw = (BNB && !STATS) ? reinterpret_cast<const T*>(a.bn_raw) : nullptr;
-        if constexpr (BNB && !STATS) {
-            // BatchNorm-backward mode (host: no activation / late addends / multiplier in this launch, full 16-byte chunks).
-            // A thread keeps ONE chunk column (NT is a multiple of CPW): its EPC channels' coefficients and sums stay in registers.
-            static_assert(NT % CPW == 0, "a thread keeps one chunk column");
-            const int cc = tid_all % CPW, ch0 = n0 + cc * EPC;
-            const bool cok = ch0 < a.Cout;
-            float a0[EPC], a1[EPC], p0[EPC], p1[EPC], s0[EPC], s1[EPC];
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                const int ch = cok ? ch0 + e : 0;
-                const float g = a.bn_gamma ? a.bn_gamma[ch] : 1.0f, b = a.bn_beta ? a.bn_beta[ch] : 0.0f;
-                p0[e] = a.bn_inv[ch];
-                p1[e] = -a.bn_mean[ch] * p0[e];
-                a0[e] = p0[e] * g;
-                a1[e] = p1[e] * g + b;
-                s0[e] = 0.f;
-                s1[e] = 0.f;
-            }
-            constexpr int RPT = BM * CPW / NT;  // rows per thread
-            // One row per trip, NOT unrolled, the next row's raw chunk in flight while this one is processed: this block exists in
-            // every data-gradient kernel and must stay small (unrolled 8x with both activation derivatives inlined it was 10,000
-            // instructions and cost the ordinary path 4 %).  Only SiLU / none occur behind a BatchNorm (the host checks).
-            const bool silu = a.bn_act == YMI_ACT_SILU;
-            auto zload = [&](int q) -> u32x4 {
-                const int m = m0 + tid_all / CPW + q * (NT / CPW);
-                return (q < RPT && m < a.M && cok) ? *reinterpret_cast<const u32x4*>(bnraw + out_pixel(m) * a.ldbn + ch0) : u32x4{0u, 0u, 0u, 0u};
-            };
-            u32x4 znext = zload(0);
-#pragma unroll 1
-            for (int q = 0; q < RPT; ++q) {
-                const u32x4 zcur = znext;
-                znext = zload(q + 1);
-                const int row = tid_all / CPW + q * (NT / CPW);
-                const int m = m0 + row;
-                if (m < a.M && cok) {
-                    u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
-                    T* vp = reinterpret_cast<T*>(&val);
-                    const T* zp = reinterpret_cast<const T*>(&zcur);
-#pragma unroll
-                    for (int h = 0; h < EPC / 4; ++h) {
-                        float v[4], z[4];
-                        Pack<T, 4>::load(vp + 4 * h, v);
-                        Pack<T, 4>::load(zp + 4 * h, z);
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            const int e = 4 * h + r;
-                            const float g = silu_grad_f(z[r] * a0[e] + a1[e]);
-                            const float u = v[r] * (silu ? g : 1.0f);
-                            s0[e] += u;
-                            s1[e] += u * (z[r] * p0[e] + p1[e]);
-                            v[r] = u;
-                        }
-                        Pack<T, 4>::store(vp + 4 * h, v);
-                    }
-                    *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch0) = val;
-                }
-            }
-            // per-channel sums of the workgroup: NT / CPW threads share a chunk column; fixed order (deterministic)
-            __syncthreads();  // everyone has read its part of the output image: reuse it
-            float* red2 = reinterpret_cast<float*>(smem);  // [NT / CPW][2][BN]
-            const int rg_ = tid_all / CPW;
-#pragma unroll
-            for (int e = 0; e < EPC; ++e) {
-                red2[(rg_ * 2 + 0) * BN + cc * EPC + e] = s0[e];
-                red2[(rg_ * 2 + 1) * BN + cc * EPC + e] = s1[e];
-            }
-            __syncthreads();
-            if (tid_all < 2 * BN) {
-                const int which = tid_all / BN, chl = tid_all % BN;
-                float sum = 0.f;
-                for (int q = 0; q < NT / CPW; ++q) sum += red2[(q * 2 + which) * BN + chl];
-                const int ch = n0 + chl;
-                if (ch < a.Cout) a.bn_partials[((int64_t)mb * 2 + which) * a.Cout + ch] = sum;
-            }
-        } else
         if (!post) {
 #pragma unroll 4
             for (int idx = tid_all; idx < BM * CPW; idx += NT) {  // every wave of the workgroup stores
@@ -620,31 +470,28 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
     YMI_STAMP_MARK(5);  // stores issued
 }
 
-// SPEC: wave specialisation.  512-thread workgroup: waves 0-3 multiply (LDS fragment reads + MFMA, the same 2x2 wave grid),
-// waves 4-7 only load (address generation + LDS-DMA into an NS-deep ring, counted vmcnt).  An LDS-DMA piece costs its
-// issuing wave 100-185 cycles inside a phase that also carries fragment reads and MFMAs (MI355X_MICROARCH.md, LDS-DMA
-// piece issue cost): 8 pieces per K step on the multiplying waves cost more than their 32 MFMAs (512 cycles) - the
-// reason ring depth never helped the unspecialised kernel.  Each SIMD now holds one multiplying and one loading wave
-// of the workgroup; the two roles meet at ONE barrier per K step.
-// NTHR = 512 without SPEC: eight waves that all load and multiply (256x128 tiles in a 4x2 wave grid of 64x64 wave tiles:
-// 0.75x the operand bytes per FLOP of the 128x128 tile at the same registers per wave).
-// PP: ping-pong.  512-thread workgroup, 256-row tile: waves 0-3 own rows 0-127, waves 4-7 rows 128-255, and the two halves run
-// half a K step apart.  A half's step is a MEMORY phase (fragment reads of step k into registers, its share of the LDS-DMA
-// pieces of step k+2, waits) followed by a COMPUTE phase (32 MFMAs on registers only), every phase ends at a workgroup
-// barrier, so each SIMD always holds one wave in its memory phase beside one in its compute phase (the arrangement
-// MI355X_MICROARCH.md, Two waves per SIMD, describes) instead of two waves in the same phase.  Three LDS stages: the pieces
-// of step k+2 overwrite the stage of step k-1, which both halves finished reading at least one phase earlier.
-template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, bool SPEC = false, int NTHR = (SPEC ? 512 : 256), bool PP = false, bool BNB = false>
+// The kernel has two forms.
+// Default (NTHR = 256): four waves in a WM x WN grid, an NS-stage LDS ring, one barrier per K step (see the file header).
+// PP, ping-pong (NTHR = 512, 256-row tile): waves 0-3 own rows 0-127, waves 4-7 rows 128-255, and the two halves run half a K step
+// apart.  A half's step is a MEMORY phase (fragment reads of step k into registers, its share of the LDS-DMA pieces of step k+2,
+// waits) followed by a COMPUTE phase (32 MFMAs on registers only), every phase ends at a workgroup barrier, so each SIMD always
+// holds one wave in its memory phase beside one in its compute phase (the arrangement MI355X_MICROARCH.md, Two waves per SIMD,
+// describes) instead of two waves in the same phase.  Three LDS stages: the pieces of step k+2 overwrite the stage of step k-1,
+// which both halves finished reading at least one phase earlier.
+// (Round-2 variants that measured slower - wave specialisation, a lockstep 256x128 tile, ring depths 1 / 3, pieces interleaved
+// with the MFMAs, LDS-resident 3x3 input rows in linear pixel order, BatchNorm-backward sums in the data-gradient epilogue -
+// were removed in round 3; their tables are profiles/r02_conv_bench_*.txt and profiles/r02_bn_bwd_fuse.txt, the code is in git.)
+template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, int NTHR = 256, bool PP = false>
 __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int TM = BM / WM / 16, TN = BN / WN / 16;
     constexpr int ROWB = CPR * 16;                    // bytes per LDS row = K step per row (64: 32 bf16 / 16 f32; 128: 64 bf16)
-    constexpr int LT = SPEC ? 256 : NTHR;             // threads that issue loads
+    constexpr int LT = NTHR;                          // threads that issue loads (all of them)
     constexpr int RPI = LT / CPR, RPW = 64 / CPR;     // rows filled per block-wide / per wave load instruction
     constexpr int NA = (BM * CPR + LT - 1) / LT, NB = (BN * CPR + LT - 1) / LT;
     constexpr int STAGE = (BM + BN) * ROWB;
     static_assert(CPR == 4 || (CPR == 8 && FAST), "128-byte rows need tap-uniform K steps");
-    static_assert(WM * WN == (SPEC ? 4 : NTHR / 64), "one wave tile per multiplying wave");
+    static_assert(WM * WN == NTHR / 64, "one wave tile per wave");
     static_assert((BM * CPR) % LT == 0, "every loading wave issues all A loads");
     extern __shared__ __attribute__((aligned(16))) char smem[];
 #ifdef YMI_STAMPS
@@ -654,8 +501,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     constexpr int NT = NTHR;
     const int tid_all = threadIdx.x, lane = tid_all & 63;
     const int wave_all = __builtin_amdgcn_readfirstlane(tid_all >> 6);  // provably wave-uniform: LDS-DMA bases go to M0 without a waterfall loop
-    const bool loader = !SPEC || wave_all >= 4, consumer = !SPEC || wave_all < 4;
-    const int tid = SPEC ? (tid_all & 255) : tid_all, wave = SPEC ? (wave_all & 3) : wave_all;  // index inside the role's waves
+    const int tid = tid_all, wave = wave_all;
     const int wm = wave / WN, wn = wave % WN;
     YMI_STAMP_DECL
     // XCD-aware order: workgroups are dealt round-robin to the 8 XCDs (id & 7), each with its own L2.  Every XCD gets a
@@ -788,29 +634,6 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
         }
     };
 
-    // one LDS-DMA piece of a FAST K step (pieces 0..NA-1: A rows, NA..NA+NB-1: B rows; the last one advances the tap)
-    auto piece_of = [&](int s, auto pc) {
-        constexpr int p = decltype(pc)::value;
-        char* As = smem + s * STAGE;
-        char* Bs = As + BM * ROWB;
-        if constexpr (p < NA) {
-            __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[p], (lptr_t)(As + (p * LT + wave * 64) * 16), 16, 0, 0);
-            a_ptr[p] += a_inc[p];
-        } else {
-            constexpr int j = p - NA;
-            if ((wave * RPW + RPI * j) < BN) {  // wave-uniform
-                __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[j], (lptr_t)(Bs + (j * LT + wave * 64) * 16), 16, 0, 0);
-                b_ptr[j] += b_inc[j];
-            }
-        }
-        if constexpr (p == NA + NB - 1) {
-            if (--left == 0) {  // next tap (scalar branch)
-                left = steps_per_tap;
-                if (++tap_s < a.ntaps) setup_tap(tap_s);
-            }
-        }
-    };
-
     YMI_STAMP_MARK(0);  // prologue (address set-up) done
     f32x4 acc[TN][TM];
 #pragma unroll
@@ -824,7 +647,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     const bool b_wave = (BN >= RPI) || (wave * RPW < BN);
     const int nkt = (a.KC + CPR - 1) / CPR;
     if constexpr (PP) {
-        static_assert(NTHR == 512 && NS == 3 && !SPEC && FAST && std::is_same<T, bf16_t>::value && WM == 4, "ping-pong form: 512 threads, 3 stages, bf16");
+        static_assert(NTHR == 512 && NS == 3 && FAST && std::is_same<T, bf16_t>::value && WM == 4, "ping-pong form: 512 threads, 3 stages, bf16");
         const int half = wave_all >> 2;  // 0: rows 0..BM/2-1 (starts first), 1: the other rows, half a step behind
         bf16x8 wf[CPR / 4][TN], xf[CPR / 4][TM];
         issue(0);
@@ -922,23 +745,13 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             }
         }
         if (half == 0) asm volatile("s_barrier" ::: "memory");  // the first half waits out the second half's last phase
-    } else if constexpr (NS == 1) {
-        // single LDS stage: no overlap inside a workgroup, half the LDS, so twice the resident workgroups overlap each other
-        for (int kt = 0; kt < nkt; ++kt) {
-            issue(0);
-            wait_vmcnt_barrier<0>();
-            Mma<T>::template step<TM, TN, CPR>(smem, smem + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
-            asm volatile("s_barrier" ::: "memory");  // everyone has read the stage before it is refilled
-        }
     } else {
-    if (loader) {
+        static_assert(NS >= 2, "the ring needs a stage to fill while another is multiplied");
 #pragma unroll
         for (int s = 0; s < NS - 1; ++s)
             if (s < nkt) issue(s);
-    }
-    for (int kt = 0; kt < nkt; ++kt) {
-        YMI_STAMP(kt);  // 0: step start
-        if (loader) {
+        for (int kt = 0; kt < nkt; ++kt) {
+            YMI_STAMP(kt);  // 0: step start
             // K step kt has landed when at most the loads of the NS-2 younger steps are outstanding
             if (kt + NS - 2 < nkt) {
                 if (b_wave) wait_vmcnt_barrier<LPT_FULL * (NS - 2)>();
@@ -948,26 +761,12 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             }
             YMI_STAMP(kt);  // 1: past the wait + barrier
             // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
-            if constexpr (YMI_PIECE_INTERLEAVE && FAST && !SPEC && std::is_same<T, bf16_t>::value && (CPR / 4) * TM * TN >= NA + NB) {
-                if (kt + NS - 1 < nkt) {  // ... with the pieces spread between this step's MFMAs
-                    const int sn = (kt + NS - 1) % NS;
-                    const char* As = smem + (kt % NS) * STAGE;
-                    Mma<T>::template step_issue<TM, TN, CPR, NA + NB>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc, [&](auto pc) { piece_of(sn, pc); });
-                    continue;
-                }
-            } else {
-                if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
-            }
-        } else {
-            asm volatile("s_barrier" ::: "memory");  // the loading waves waited for step kt's pieces before they arrived here
-        }
-        YMI_STAMP(kt);  // 2: pieces issued
-        if (consumer) {
+            if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
+            YMI_STAMP(kt);  // 2: pieces issued
             const char* As = smem + (kt % NS) * STAGE;
             Mma<T>::template step<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
+            YMI_STAMP(kt);  // 3: fragments read, MFMAs issued
         }
-        YMI_STAMP(kt);  // 3: fragments read, MFMAs issued
-    }
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
     YMI_STAMP_DUMP;
@@ -978,145 +777,12 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     // workgroup stores it as 16-byte chunks along C, so every store instruction writes whole 128-byte lines
     // (per-lane 8-byte stores to 16 different rows cost 2-3x the time of the same bytes stored this way).
 #ifdef YMI_STAMPS
-    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT, BNB>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer, stamp_on, wave_all, stamp_mt0);
+    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, stamp_on, wave_all, stamp_mt0);
 #else
-    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT, BNB>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, consumer);
+    igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     YMI_STAMP_MARK(2);  // epilogue done, stores retired
-}
-
-// ---- 3x3 stride-1 convolution (forward and data gradient) with the input rows of the tile resident in LDS ---------------
-// The GEMM kernel above fetches the A operand once per TAP: nine 16 KB tiles per 64 input channels, although the nine
-// tiles of a 128-pixel block are the same ~130+2W pixels shifted by (dh*W + dw) rows.  All variants of that kernel run
-// at the same speed whatever the ring depth, occupancy, wave roles or fragment scheduling (profiles/r02_conv_bench_*.txt):
-// what they share is the byte count through the L2 -> LDS path.  Here the 128 + 2(W+1) pixel rows a block needs are
-// loaded ONCE per 64-channel chunk (an "image" in LDS) and every tap reads its fragments from the image at a shifted row;
-// only the weight tile is fetched per tap.  Bytes per chunk: (128 + 2W + 2) * 128 + 9 * BN * 128 instead of
-// 9 * (128 + BN) * 128 (W = 40, BN = 128: 174 KB vs 295 KB).
-// Shifted rows cross image-row and image boundaries (the left neighbour of pixel (y, 0) is pixel (y-1, W-1) in linear
-// order), so each lane zeroes its activation fragment for the taps its pixel does not have (4 v_cndmask per fragment).
-template <int BN, int CPR, bool STATS>
-__global__ __launch_bounds__(256) void conv3_kernel(IgemmArgs a, int R, int a_bytes) {
-    typedef bf16_t T;
-    constexpr int BM = 128, WM = 2, WN = 2, TM = 4, TN = BN / WN / 16;
-    constexpr int ROWB = CPR * 16, KCH = CPR * 8;      // bytes / channels of one LDS row (one chunk of input channels)
-    constexpr int RPI = 256 / CPR;                      // rows filled per block-wide load instruction
-    constexpr int NB = (BN * CPR + 255) / 256;
-    constexpr int KS = CPR / 4;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Aimg = smem;
-    char* Bst = smem + a_bytes;  // [2][BN][ROWB]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l15 = lane & 15, l4 = lane >> 4;
-    const int orig = blockIdx.x, xcd = orig & 7, seq = orig >> 3;
-    const int nb = seq % a.nnb, ml = seq / a.nnb;
-    const int mb = xcd * a.mpx + ml;
-    if (mb >= a.nmb) return;
-    const int m0 = mb * BM, n0 = nb * BN;
-    const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
-    const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
-    const T* zero = reinterpret_cast<const T*>(a.zero);
-    const int W = a.W, halo = W + 1;
-    const int Cin = a.cpt * 8;
-
-    // ---- loader state: this thread's chunk column and rows -----------------------------------------------------------
-    const int lrow = tid / CPR;
-    const int csrc = CPR == 4 ? ((tid & 3) ^ ((-(lrow >> 2)) & 3)) : ((tid & 7) ^ ((lrow >> 1) & 7));  // swizzle is invariant under row += RPI
-    const int nai = (R * CPR + 255) / 256;
-    const T* b_row[NB];
-    bool b_ok[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int rn = lrow + RPI * j, n = n0 + rn;
-        b_ok[j] = n < a.Cout && rn < BN;
-        b_row[j] = wg + (int64_t)(b_ok[j] ? n : 0) * a.ktot + csrc * 8;
-    }
-    auto issue_a = [&](int cin0) {
-        for (int i = 0; i < nai; ++i) {
-            const int row = lrow + RPI * i;
-            const int64_t p = (int64_t)m0 - halo + row;
-            const bool ok = row < R && p >= 0 && p < a.M;
-            const T* src = ok ? xg + p * a.ldx + cin0 + csrc * 8 : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Aimg + (i * 256 + wave * 64) * 16), 16, 0, 0);
-        }
-    };
-    auto issue_b = [&](int stage, int tap, int cin0) {
-        char* Bs = Bst + stage * (BN * ROWB);
-#pragma unroll
-        for (int j = 0; j < NB; ++j) {
-            if ((wave * (64 / CPR) + RPI * j) < BN) {  // wave-uniform
-                const T* src = b_ok[j] ? b_row[j] + tap * Cin + cin0 : zero;
-                __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Bs + (j * 256 + wave * 64) * 16), 16, 0, 0);
-            }
-        }
-    };
-
-    // ---- consumer state: per pixel tile of this lane, which taps its pixel lacks -------------------------------------
-    int flags[TM];
-#pragma unroll
-    for (int tm = 0; tm < TM; ++tm) {
-        const int m = m0 + wm * 64 + tm * 16 + l15;
-        const int mm = m < a.M ? m : 0;
-        const int t = fast_div(mm, a.wo_mul, a.wo_shr, a.Wo);
-        const int x = mm - t * a.Wo;
-        const int n = fast_div(t, a.ho_mul, a.ho_shr, a.Ho);
-        const int y = t - n * a.Ho;
-        flags[tm] = (x == 0 ? 1 : 0) | (x == W - 1 ? 2 : 0) | (y == 0 ? 4 : 0) | (y == a.H - 1 ? 8 : 0) | (m < a.M ? 0 : 16);
-    }
-    const int swb = CPR == 4 ? ((-(l15 >> 2)) & 3) : ((l15 >> 1) & 7);  // weight tile: fragment rows start at multiples of 16
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int nchunks = a.cpt / CPR;
-    for (int ck = 0; ck < nchunks; ++ck) {
-        const int cin0 = ck * KCH;
-        if (ck > 0) asm volatile("s_barrier" ::: "memory");  // every wave has finished reading the previous chunk's image and weight tiles
-        issue_a(cin0);
-        issue_b(0, 0, cin0);
-        for (int tap = 0; tap < a.ntaps; ++tap) {
-            wait_vmcnt_barrier<0>();  // this tap's weight tile (and, at tap 0, the image) has landed; nobody still reads the other stage
-            if (tap + 1 < a.ntaps) issue_b((tap + 1) & 1, tap + 1, cin0);
-            const int dh = (int)((a.tap_dh >> (4 * tap)) & 15) - 8;
-            const int dw = (int)((a.tap_dw >> (4 * tap)) & 15) - 8;
-            const int tapmask = (dw < 0 ? 1 : 0) | (dw > 0 ? 2 : 0) | (dh < 0 ? 4 : 0) | (dh > 0 ? 8 : 0) | 16;
-            const int shift = halo + dh * W + dw + wm * 64 + l15;  // image row of this lane's pixel for pixel tile 0
-            const char* Bs = Bst + (tap & 1) * (BN * ROWB);
-            bf16x8 wf[KS][TN], xf[KS][TM];
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-                    wf[ks][tn] = *reinterpret_cast<const bf16x8*>(Bs + (wn * TN * 16 + tn * 16 + l15) * ROWB + (((4 * ks + l4) ^ swb) << 4));
-#pragma unroll
-                for (int tm = 0; tm < TM; ++tm) {
-                    const int row = shift + tm * 16;
-                    const int sw = CPR == 4 ? ((-(row >> 2)) & 3) : ((row >> 1) & 7);
-                    xf[ks][tm] = *reinterpret_cast<const bf16x8*>(Aimg + row * ROWB + (((4 * ks + l4) ^ sw) << 4));
-                }
-            }
-#pragma unroll
-            for (int tm = 0; tm < TM; ++tm) {
-                if (flags[tm] & tapmask) {
-#pragma unroll
-                    for (int ks = 0; ks < KS; ++ks) xf[ks][tm] = bf16x8{};
-                }
-            }
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-                for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-                    for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");  // epilogue reuses LDS
-    igemm_epilogue<T, BM, BN, WM, WN, STATS, 256>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid, true);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1130,9 +796,7 @@ struct TileChoice {
 // Largest tile that still yields ~1.5 workgroups per CU (measured on the 40x40 / 20x20 layers of the model: 400 tiles of
 // 128x128 beat 800 of 64x128 by 25-30 %, and below that 128x64, then 64x64, win); short-K GEMMs (K <= 384) are
 // prologue/epilogue-dominated and run best as 128x64 (three resident workgroups per CU).
-static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats, bool bf16 = true) {
-    (void)stats;
-    const bool stats_bf16_hint = bf16;  // the 256x128 tile exists for bf16 only
+static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool bf16) {
     TileChoice t;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((cout + bn - 1) / bn); };
     static const int enough_env = getenv("YMI_IGEMM_ENOUGH") ? atoi(getenv("YMI_IGEMM_ENOUGH")) : 400;  // tuning knob
@@ -1150,24 +814,20 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats,
     } else {
         t.bm = 64; t.bn = 64;
     }
-    // 256x128 (eight waves): only where it still leaves >= `big_env` workgroups and operand rows are 128 bytes
-    static const int big_env = getenv("YMI_IGEMM_BIG") ? atoi(getenv("YMI_IGEMM_BIG")) : 0;  // 0: off (measured 5-30 % SLOWER wherever it applies: profiles/r02_conv_bench_big.txt)
-    if (big_env > 0 && stats_bf16_hint && cout >= 128 && ktot % 64 == 0 && blocks(256, 128) >= big_env) {
-        t.bm = 256; t.bn = 128;
-    }
-    // ping-pong form of the same tile (the two 128-row halves half a K step apart), where it leaves >= `pp_env` workgroups
-    // Default ON from 300 workgroups (measured, profiles/r02_conv_bench_pp64.txt: with 64-byte rows - three 24 KB stages, TWO resident
-    // workgroups per CU - it wins 5-19 % on every layer that yields >= 400 such tiles and loses 15-25 % at 200; step 14.71 -> 14.38 ms).
-    static const int pp_env = getenv("YMI_IGEMM_PP") ? atoi(getenv("YMI_IGEMM_PP")) : 300;
-    if (pp_env > 0 && stats_bf16_hint && cout >= 128 && ktot % 64 == 0 && blocks(256, 128) >= pp_env) {
+    // ping-pong form of the 256x128 tile (the two 128-row halves half a K step apart), where it leaves >= `pp_env` workgroups.
+    // Default from 300 workgroups (measured, profiles/r02_conv_bench_pp64.txt: 64-byte rows - three 24 KB stages, TWO resident
+    // workgroups per CU - win 5-19 % on every layer that yields >= 400 such tiles and lose 15-25 % at 200; step 14.71 -> 14.38 ms).
+    static const int pp_env = getenv("YMI_IGEMM_PP") ? atoi(getenv("YMI_IGEMM_PP")) : 300;  // tuning knob (0: off)
+    if (pp_env > 0 && bf16 && cout >= 128 && ktot % 32 == 0 && blocks(256, 128) >= pp_env) {
         t.bm = 256; t.bn = 128; t.pp = true;
     }
-    static const char* tile_env = getenv("YMI_IGEMM_TILE");  // "bm,bn": force a tile (tuning knob)
+    static const char* tile_env = getenv("YMI_IGEMM_TILE");  // "bm,bn": force a tile (tools/conv_bench.py sweeps)
     if (tile_env) {
         int bm = 0, bn = 0;
         if (sscanf(tile_env, "%d,%d", &bm, &bn) == 2 && (bn <= 32 ? cout <= 32 : true)) {
             t.bm = bm;
             t.bn = bn;
+            t.pp = bm == 256;
         }
     }
     return t;
@@ -1175,7 +835,7 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool stats,
 
 // Row width of the LDS operand images: 128-byte rows (K step = 64 bf16) whenever Cin allows it: every LDS-DMA
 // instruction then touches 8 full 128-byte cache lines instead of 16 half lines, and there is one barrier per
-// 32 MFMAs per wave instead of per 16.  YMI_IGEMM_ROWB=64 forces the narrow form (tuning knob).
+// 32 MFMAs per wave instead of per 16.
 template <typename T, bool STATS>
 static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStream_t stream) {
     IgemmMulti P{};
@@ -1191,16 +851,11 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     const IgemmArgs& a = P.c[0];
     dim3 grid((unsigned)(8 * mpx * a.nnb * ncls));
     const bool fast = (a.cpt % 4) == 0;
-    static const int rowb_env = getenv("YMI_IGEMM_ROWB") ? atoi(getenv("YMI_IGEMM_ROWB")) : 0;
-    static const int spec_env = getenv("YMI_IGEMM_SPEC") ? atoi(getenv("YMI_IGEMM_SPEC")) : 0;  // 1: wave-specialised form (measured 12-20 % SLOWER, profiles/r02_conv_bench_spec.txt: kept as a knob)
-    const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0 && rowb_env != 64;
-    const bool spec = wide && spec_env != 0;  // wave-specialised form: the bf16 128-byte-row kernels (every layer but the first)
-    static const int spec_ns = getenv("YMI_IGEMM_SPEC_NS") ? atoi(getenv("YMI_IGEMM_SPEC_NS")) : 3;
-    size_t lds = (size_t)(spec ? spec_ns : 2) * (t.bm + t.bn) * (wide ? 128 : 64);
+    const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0;
+    size_t lds = (size_t)2 * (t.bm + t.bn) * (wide ? 128 : 64);
     const size_t epi = (size_t)t.bm * (t.bn * sizeof(T) + 16) + (STATS ? 4 * 2 * t.bn * sizeof(float) : 0);
     if (epi > lds) lds = epi;
     unsigned nthreads = 256;
-    static const int ns_env = getenv("YMI_IGEMM_NS") ? atoi(getenv("YMI_IGEMM_NS")) : 2;  // LDS ring depth of the 128-byte-row kernels (tuning knob)
 #ifdef YMI_STAMPS
 #define YMI_STAMP_LDS 4096
 #else
@@ -1214,21 +869,7 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     } while (0)
 #define YMI_LAUNCH(BM, BN, WM, WN)                                                              \
     do {                                                                                        \
-        if constexpr (!STATS) {                                                                 \
-            if (a.bn_raw) { /* BatchNorm-backward epilogue: its own instantiations of the default form */ \
-                if constexpr (std::is_same<T, bf16_t>::value) {                                 \
-                    if (wide) { YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, false, false, 256, false, true>)); break; } \
-                }                                                                               \
-                if (fast) YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, true, false, false, 256, false, true>)); \
-                else YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, false, false, false, 256, false, true>)); \
-                break;                                                                          \
-            }                                                                                   \
-        }                                                                                       \
         if constexpr (std::is_same<T, bf16_t>::value) {                                         \
-            if (spec && spec_ns == 2) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS, true>)); break; } \
-            if (spec) { nthreads = 512; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 3, 8, true, STATS, true>)); break; } \
-            if (wide && ns_env == 1) { lds = (size_t)(t.bm + t.bn) * 128 > epi ? (size_t)(t.bm + t.bn) * 128 : epi; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 1, 8, true, STATS>)); break; } \
-            if (wide && ns_env == 3) { lds = (size_t)3 * (t.bm + t.bn) * 128 > epi ? (size_t)3 * (t.bm + t.bn) * 128 : epi; YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 3, 8, true, STATS>)); break; } \
             if (wide) { YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 8, true, STATS>)); break; } \
         }                                                                                       \
         if (fast) YMI_LAUNCH1((igemm_kernel<T, BM, BN, WM, WN, 2, 4, true, STATS>));            \
@@ -1236,23 +877,11 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     } while (0)
     if (t.bm == 256 && t.bn == 128) {
         if constexpr (std::is_same<T, bf16_t>::value) {
-            static const int pp_rowb_chk = getenv("YMI_IGEMM_PP_ROWB") ? atoi(getenv("YMI_IGEMM_PP_ROWB")) : 64;
-            if (t.pp && pp_rowb_chk == 64) YMI_CHECK_ARG(fast, "igemm: the ping-pong tile needs input channels that are a multiple of 32");
-            else YMI_CHECK_ARG(wide, "igemm: the 256x128 tile needs 128-byte operand rows");
+            YMI_CHECK_ARG(t.pp && fast, "igemm: the 256x128 ping-pong tile needs input channels that are a multiple of 32");
             nthreads = 512;
-            static const int big_ns = getenv("YMI_IGEMM_BIG_NS") ? atoi(getenv("YMI_IGEMM_BIG_NS")) : 2;  // ring depth of the 256x128 tile (3: 144 KB of LDS, two K steps in flight)
-            lds = (size_t)(big_ns == 3 ? 3 : 2) * (256 + 128) * 128;
+            lds = (size_t)3 * (256 + 128) * 64;  // 64-byte rows (32-deep K steps): 72 KB, two workgroups per CU (128-byte rows: one, slower)
             if (epi > lds) lds = epi;
-            static const int pp_rowb = getenv("YMI_IGEMM_PP_ROWB") ? atoi(getenv("YMI_IGEMM_PP_ROWB")) : 64;  // 64 (default): 32-deep K steps, 72 KB of LDS, two workgroups per CU; 128: one (slower)
-            if (t.pp && pp_rowb == 64) {
-                lds = (size_t)3 * (256 + 128) * 64;
-                if (epi > lds) lds = epi;
-                YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 4, true, STATS, false, 512, true>));
-            } else if (t.pp) {
-                lds = (size_t)3 * (256 + 128) * 128;
-                YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512, true>));
-            } else if (big_ns == 3) YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 8, true, STATS, false, 512>));
-            else YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 2, 8, true, STATS, false, 512>));
+            YMI_LAUNCH1((igemm_kernel<T, 256, 128, 4, 2, 3, 4, true, STATS, 512, true>));
         } else {
             ymi_set_error("igemm: the 256x128 tile is bf16 only");
             return YMI_EINVAL;
@@ -1272,6 +901,7 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
     return YMI_OK;
 }
 
+
 bool ymi_prof_enabled();
 int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, double peak_tflops);
 void ymi_prof_stop(hipStream_t stream, int idx);
@@ -1284,7 +914,7 @@ static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats,
         mmax = arr[i].M > mmax ? arr[i].M : mmax;
         kmax = arr[i].ktot > kmax ? arr[i].ktot : kmax;
     }
-    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout, kmax, stats, dtype == YMI_BF16);
+    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout, kmax, dtype == YMI_BF16);
     if (host_blocks) *host_blocks = (arr[0].M + t.bm - 1) / t.bm;
     int prof = -1;
     if (ymi_prof_enabled()) {
@@ -1306,58 +936,8 @@ static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats,
     return rc;
 }
 
-// the LDS-resident-input kernel for 3x3 stride-1 problems; returns 1 when the problem is not of that kind
-static int launch_conv3(const IgemmArgs& a0, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
-    static const int env = getenv("YMI_CONV3") ? atoi(getenv("YMI_CONV3")) : 0;  // off: measured 5-50 % SLOWER than the per-tap gather although it moves 40 % fewer bytes (profiles/r02_conv_bench_conv3.txt)
-    if (!env || dtype != YMI_BF16 || a0.ntaps != 9 || a0.s_in != 1 || a0.s_out != 1 || a0.H != a0.Ho || a0.W != a0.Wo || a0.Hy != a0.Ho || a0.Wy != a0.Wo) return 1;
-    if (a0.cpt % 4 != 0 || a0.W < 2 || a0.H < 2) return 1;
-    for (int t = 0; t < 9; ++t) {
-        const int dh = (int)((a0.tap_dh >> (4 * t)) & 15) - 8, dw = (int)((a0.tap_dw >> (4 * t)) & 15) - 8;
-        if (dh < -1 || dh > 1 || dw < -1 || dw > 1) return 1;
-    }
-    const int cpr = (a0.cpt % 8) == 0 ? 8 : 4;
-    const int bn = a0.Cout <= 64 ? 64 : 128;
-    const int R = 128 + 2 * (a0.W + 1);
-    const int a_bytes = (R * cpr + 255) / 256 * 4096;
-    size_t lds = (size_t)a_bytes + (size_t)2 * bn * cpr * 16;
-    const size_t epi = (size_t)128 * (bn * 2 + 16) + (stats ? 4 * 2 * bn * sizeof(float) : 0);
-    if (epi > lds) lds = epi;
-    if (lds > 96 * 1024) return 1;  // wide maps with many channels per row: the image would leave one workgroup per CU
-    IgemmArgs a = a0;
-    a.nmb = (a.M + 127) / 128;
-    a.nnb = (a.Cout + bn - 1) / bn;
-    a.mpx = (a.nmb + 7) / 8;
-    if (host_blocks) *host_blocks = a.nmb;
-    dim3 grid((unsigned)(8 * a.mpx * a.nnb));
-    int prof = -1;
-    if (ymi_prof_enabled()) {
-        const double flop = 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot;
-        const double bytes = (double)a.ktot * a.Cout * 2.0 + (double)a.M * a.Cout * 2.0 * (a.res ? 2.0 : 1.0) + (double)a.M * a.cpt * 16.0;
-        prof = ymi_prof_start(stream, 0, flop, bytes, 2500.0);
-    }
-#define YMI_C3(BN_, CPR_)                                                                                                         \
-    do {                                                                                                                          \
-        if (stats) {                                                                                                              \
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<BN_, CPR_, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);  \
-            hipLaunchKernelGGL((conv3_kernel<BN_, CPR_, true>), grid, dim3(256), lds, stream, a, R, a_bytes);                      \
-        } else {                                                                                                                  \
-            if (lds > 64 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv3_kernel<BN_, CPR_, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-            hipLaunchKernelGGL((conv3_kernel<BN_, CPR_, false>), grid, dim3(256), lds, stream, a, R, a_bytes);                     \
-        }                                                                                                                         \
-    } while (0)
-    if (bn == 128 && cpr == 8) YMI_C3(128, 8);
-    else if (bn == 128) YMI_C3(128, 4);
-    else if (cpr == 8) YMI_C3(64, 8);
-    else YMI_C3(64, 4);
-#undef YMI_C3
-    ymi_prof_stop(stream, prof);
-    YMI_CHECK_LAUNCH("conv3");
-    return YMI_OK;
-}
 
 int ymi_launch_igemm(const IgemmArgs& a, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
-    const int rc = launch_conv3(a, dtype, stats, host_blocks, stream);
-    if (rc != 1) return rc;
     return launch_igemm_n(&a, 1, dtype, stats, host_blocks, stream);
 }
 
@@ -1457,20 +1037,8 @@ extern "C" int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_pac
     return ymi_conv2d_bwd_data_add(dy, w_dgrad_packed, cin, kh, kw, stride, nullptr, nullptr, dx, stream);
 }
 
-struct BnBwdFuse {  // BatchNorm-backward mode of a stride-1 data gradient (see IgemmArgs::bn_raw)
-    const ymi_tensor* raw;
-    const float* gamma;
-    const float* beta;
-    const float* mean;
-    const float* inv;
-    int32_t act;
-    float* partials;
-    int64_t partial_floats;  // capacity of `partials`
-    int64_t* rows_out;       // partial rows written (host value)
-};
 static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
-                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream,
-                      const BnBwdFuse* bn = nullptr);
+                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream);
 
 extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw,
                                        int64_t stride, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream) {
@@ -1478,18 +1046,8 @@ extern "C" int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad
 }
 
 static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
-                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream,
-                      const BnBwdFuse* bn) {
+                      const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* mul, int32_t mul_act, const ymi_tensor* dx, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && w_dgrad_packed, "conv2d_bwd_data: bad tensor");
-    if (bn) {
-        const int epc = (int)(16 / ymi_esize(dx->dtype));
-        YMI_CHECK_ARG(stride == 1 && !mul, "conv2d_bwd_data_bn: stride-1 data gradients only");
-        YMI_CHECK_ARG(bn->act == YMI_ACT_SILU || bn->act == YMI_ACT_NONE, "conv2d_bwd_data_bn: activation must be SiLU or none");
-        YMI_CHECK_ARG(ymi_tensor_ok(bn->raw) && ymi_same_shape(bn->raw, dx) && bn->raw->dtype == dx->dtype && bn->mean && bn->inv && bn->partials && bn->rows_out,
-                      "conv2d_bwd_data_bn: the producer's raw output must have the gradient's shape");
-        YMI_CHECK_ARG(dx->ld % epc == 0 && ((uintptr_t)dx->data & 15) == 0 && bn->raw->ld % epc == 0 && ((uintptr_t)bn->raw->data & 15) == 0 && cin % epc == 0,
-                      "conv2d_bwd_data_bn: 16-byte-aligned rows");
-    }
     if (mul) {
         const int epc = (int)(16 / ymi_esize(dx->dtype));
         YMI_CHECK_ARG(ymi_tensor_ok(mul) && ymi_same_shape(mul, dx) && mul->dtype == dx->dtype && mul->ld % 4 == 0 &&
@@ -1536,10 +1094,6 @@ static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t 
             pack_taps(dh, dw, nt, &a.tap_dh, &a.tap_dw);
             a.act = YMI_ACT_NONE;
             a.mul = mul ? mul->data : nullptr; a.ldmul = mul ? mul->ld : 0; a.mul_act = mul_act;
-            if (bn) {
-                a.bn_raw = bn->raw->data; a.ldbn = bn->raw->ld; a.bn_gamma = bn->gamma; a.bn_beta = bn->beta; a.bn_mean = bn->mean; a.bn_inv = bn->inv;
-                a.bn_act = bn->act; a.bn_partials = bn->partials;
-            }
             a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0) &&
                           (!add1 || (add1->ld % 4 == 0 && ((uintptr_t)add1->data) % (4 * es) == 0)) &&
                           (!add2 || (add2->ld % 4 == 0 && ((uintptr_t)add2->data) % (4 * es) == 0));
@@ -1551,37 +1105,14 @@ static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t 
         }
         woff += (int64_t)nt * dy->c * cin;
     }
-    static const int fuse_env = getenv("YMI_DGRAD_FUSE") ? atoi(getenv("YMI_DGRAD_FUSE")) : 1;  // 0: one launch per parity class
-    // (measured: fusing pays from 64 output channels up; the 32-channel layer 1 is 6 % faster class by class)
-    if (bn) {  // one class (stride 1); the launcher reports the M blocks of the tile it chose = partial rows
-        YMI_CHECK_ARG(nlaunch == 1 && classes[0].vec16, "conv2d_bwd_data_bn: needs the aligned single-launch form");
-        // the smallest tile any choice uses has 64 rows: the caller's buffer must hold that many rows
-        const int64_t worst = ((int64_t)classes[0].M + 63) / 64;
-        YMI_CHECK_ARG(bn->partial_floats >= worst * 2 * cin, "conv2d_bwd_data_bn: partials buffer %lld < %lld floats", (long long)bn->partial_floats,
-                      (long long)(worst * 2 * cin));
-        int blocks = 0;
-        const int rc = launch_igemm_n(classes, 1, dy->dtype, false, &blocks, (hipStream_t)stream);
-        *bn->rows_out = blocks;
-        return rc;
-    }
-    if (fuse_env && cin >= 64 && nlaunch > 1) return launch_igemm_n(classes, nlaunch, dy->dtype, false, nullptr, (hipStream_t)stream);
+    // the parity classes of a stride-2 data gradient as ONE multi-problem launch (measured: pays from 64 output channels up; the
+    // 32-channel layer 1 is 6 % faster class by class)
+    if (cin >= 64 && nlaunch > 1) return launch_igemm_n(classes, nlaunch, dy->dtype, false, nullptr, (hipStream_t)stream);
     for (int i = 0; i < nlaunch; ++i) {
         int rc = ymi_launch_igemm(classes[i], dy->dtype, false, nullptr, (hipStream_t)stream);
         if (rc) return rc;
     }
     return YMI_OK;
-}
-
-// Data gradient of a convolution whose INPUT was produced by a Conv-BatchNorm-activation block, with the reduce pass of that
-// block's BatchNorm backward folded into the epilogue (stride 1): dx receives u = (dgrad + add1 + add2) * act'(BN(raw)) and
-// `partials` [rows][2][cin] the per-workgroup sums of u and u * x^; *rows_out = rows written.  ymi_bn_act_bwd_from_partials
-// finishes that layer's backward from them.
-extern "C" int ymi_conv2d_bwd_data_bn(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, const ymi_tensor* add1,
-                                      const ymi_tensor* add2, const ymi_tensor* bn_raw, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
-                                      const float* bn_invstd, int32_t bn_act, float* partials, int64_t partial_floats, int64_t* rows_out,
-                                      const ymi_tensor* dx, void* stream) {
-    BnBwdFuse bn{bn_raw, bn_gamma, bn_beta, bn_mean, bn_invstd, bn_act, partials, partial_floats, rows_out};
-    return dgrad_impl(dy, w_dgrad_packed, cin, kh, kw, 1, add1, add2, nullptr, YMI_ACT_NONE, dx, stream, &bn);
 }
 
 // ---- SwinBlock MLP (swin_block.py:33,53: Linear(C, 4C) -> GELU -> Linear(4C, C), + the skip) ------------------------------------

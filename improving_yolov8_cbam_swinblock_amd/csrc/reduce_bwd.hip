@@ -390,30 +390,6 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     return launch_bn_apply(dout, raw, draw, act, coef, s);
 }
 
-// The rest of a Conv-BN-act block's backward when the data-gradient launch that produced its output gradient already multiplied
-// by act' and left per-workgroup partial sums (ymi_conv2d_bwd_data_bn): final reduce (dbeta, dgamma, apply coefficients) and the
-// apply pass  draw = u * c0 - raw * c1 - c2.  No reduce pass over the tensors.  workspace: 5 * C floats.
-extern "C" int ymi_bn_act_bwd_from_partials(const ymi_tensor* u, const ymi_tensor* raw, const float* gamma, const float* save_mean, const float* save_invstd,
-                                            const float* beta, const float* partials, int64_t rows, const ymi_tensor* draw, float* dgamma, float* dbeta,
-                                            void* workspace, size_t workspace_bytes, void* stream) {
-    YMI_CHECK_ARG(ymi_tensor_ok(u) && ymi_tensor_ok(raw) && ymi_tensor_ok(draw) && ymi_same_shape(u, raw) && ymi_same_shape(u, draw), "bn_act_bwd_from_partials: shapes");
-    YMI_CHECK_ARG(u->dtype == raw->dtype && raw->dtype == draw->dtype, "bn_act_bwd_from_partials: dtypes");
-    YMI_CHECK_ARG(save_mean && save_invstd && dgamma && dbeta && partials && workspace && rows > 0, "bn_act_bwd_from_partials: null argument");
-    const int64_t P = ymi_pixels(u);
-    const int C = (int)u->c;
-    YMI_CHECK_ARG(C % 4 == 0 && u->ld % 4 == 0 && raw->ld % 4 == 0 && draw->ld % 4 == 0, "bn_act_bwd_from_partials: channels must be a multiple of 4");
-    if (workspace_bytes < 5 * (size_t)C * sizeof(float)) {
-        ymi_set_error("bn_act_bwd_from_partials: workspace %zu < %zu", workspace_bytes, 5 * (size_t)C * sizeof(float));
-        return YMI_EWORKSPACE;
-    }
-    hipStream_t s = (hipStream_t)stream;
-    float* coef = (float*)workspace;
-    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, partials, (int)rows, C, dbeta, dgamma,
-                       BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef});
-    YMI_CHECK_LAUNCH("bn_act_bwd_from_partials(final)");
-    return launch_bn_apply(u, raw, draw, YMI_ACT_NONE, coef, s);
-}
-
 // dx = dy * gelu'(pre)
 template <typename T>
 __global__ void gelu_bwd_kernel(RV pre, RV dy, RV dx, int64_t P, int C) {

@@ -5,9 +5,12 @@
 // Both operands are "K-major" in memory (the reduction index m is the slow one), so tiles are staged
 // in LDS exactly as they lie in HBM ([pixel][channel] rows, filled by 16-byte LDS-DMA) and the MFMA
 // fragments are read TRANSPOSED with ds_read_b64_tr_b16 (bf16) or plain ds_read_b32 (f32 parity
-// mode, 16x16x4 MFMA).  The pixel axis is split across workgroups (grid.z); each split writes an f32
-// slab, a second kernel sums the slabs in a fixed order (deterministic, no atomics) and scatters into
-// the reference's OIHW layout.
+// mode, 16x16x4 MFMA).  The pixel axis is split across workgroups; each split writes a slab of partial
+// sums, a second kernel sums the slabs in float32 in a fixed order (deterministic, no atomics) and scatters
+// into the reference's OIHW layout.  Slabs are float32 in parity mode and bfloat16 in the bf16 path
+// (round 3): the first-level partials of a split - a sum over >= 256 pixels held in float32 registers -
+// are rounded once on their way out, the second level stays float32.  That halves the slab traffic
+// (36 MB -> 18 MB written per launch at bs 32, and the batched reduce reads half as much).
 #include <stdlib.h>
 
 #include <type_traits>
@@ -41,7 +44,8 @@ extern "C" int ymi_debug_stamp_buffer_wgrad(void* p) {
 struct WgradArgs {
     const void* x;
     const void* dy;
-    float* slab;
+    void* slab;
+    int slab_bf16;
     const void* zero;
     int64_t ldx, ldy;
     int Mpix, H, W, Ho, Wo;
@@ -133,11 +137,10 @@ template <> struct WFrag<float> {
 
 // BM = output channels per workgroup tile: 64, or 128 for layers with >= 128 output channels (16 instead of 8 MFMAs per
 // wave and K step against the same address arithmetic: the K loop is instruction-issue-bound, not MFMA-bound)
-// BNW = (tap, ci) columns per workgroup tile: 128, or 256 with BM = 128 as a 512-thread workgroup (eight waves in a 2 x 4 grid of
-// 64x64 wave tiles: a 128x256 tile moves 24 KB per K step for twice the MFMAs of the 128x128 tile's 16 KB at the same registers
-// per wave; see wgrad_bn for the measurements).
-template <typename T, int NS, int BM, int BNW = WG_BN, int NT = (BNW == 256 ? 512 : 256)>
-__global__ __launch_bounds__(NT, (BNW == 256 ? 4 : BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
+// (a 128x256 tile - 4 or 8 waves - measured 1.17-1.66x slower, profiles/r02_conv_bench_wgrad256.txt; removed in round 3)
+template <typename T, int NS, int BM>
+__global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
+    constexpr int BNW = WG_BN, NT = 256;
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
     constexpr int YCW = BM * ES / 16, XCW = BNW * ES / 16;            // 16-byte chunks per tile row
@@ -182,10 +185,7 @@ __global__ __launch_bounds__(NT, (BNW == 256 ? 4 : BM == 128 ? 3 : YMI_WGRAD_WAV
     const int ycc = SWZ ? ((tid % YCW) ^ ((BM == 128 ? wg_swz_x(tid / YCW) : wg_swz_y(tid / YCW)) << 1)) : (tid % YCW);
     const bool y_cok = co0 + ycc * CH < a.CoutP;
     // X loader: column chunk fixed per thread -> fixed tap / input-channel offset
-    // 256-column tile: a block-wide load instruction covers 8 rows, so piece i would start at row 8 i and flip row bit 3 - which the
-    // swizzle uses.  Its pieces go to rows  2 (wave & 1) + 8 (wave >> 1) + 4 (i & 1) + 16 (i >> 1) + (lane >> 5)  instead: row
-    // bits 0, 1 and 3 come from the thread, bits 2 and 4 from the piece, and the thread's source column chunk stays fixed.
-    static_assert(NT / XCW >= 16 || BNW != 256, "a block-wide load covers >= 16 rows, so a thread's rows share the row bits the swizzle uses");
+    static_assert(NT / XCW >= 16 || !std::is_same<T, bf16_t>::value, "bf16: a block-wide load covers >= 16 rows, so a thread's rows share the row bits the swizzle uses");
     const int xrow0 = tid / XCW;
     const int xcc = SWZ ? ((tid % XCW) ^ (wg_swz_x(xrow0) << 1)) : (tid % XCW);
     const int j = j0 + xcc * CH;
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NT, (BNW == 256 ? 4 : BM == 128 ? 3 : YMI_WGRAD_WAV
 #ifdef YMI_STAMPS
     if (wstamp_on) g_wstamp_buf[8 * 64 + 16 + wave * 8 + 6] = nk;
 #endif
-    float* slab = a.slab + (int64_t)bz * a.CoutP * a.NG;
+    const int64_t slab_off = (int64_t)bz * a.CoutP * a.NG;
     // The MFMA operands are swapped (A = the X fragment, B = the dY fragment), so a lane's four accumulator values are four
     // CONSECUTIVE (tap, ci) columns of one output channel: one 16-byte store instead of four 4-byte stores to four rows
     // (stores are issue-bound on this chip: 8 / 16 instructions per lane instead of 32 / 64).  NG is a multiple of 4.
@@ -314,7 +314,15 @@ __global__ __launch_bounds__(NT, (BNW == 256 ? 4 : BM == 128 ? 3 : YMI_WGRAD_WAV
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
             const int col = j0 + wc * 64 + c * 16 + 4 * l4;
-            if (co < a.CoutP && col < a.NG) *reinterpret_cast<f32x4*>(slab + (int64_t)co * a.NG + col) = acc[r][c];
+            if (co < a.CoutP && col < a.NG) {
+                const int64_t e = slab_off + (int64_t)co * a.NG + col;
+                if (std::is_same<T, bf16_t>::value && a.slab_bf16) {
+                    const bf16x4 v = {(bf16_t)acc[r][c][0], (bf16_t)acc[r][c][1], (bf16_t)acc[r][c][2], (bf16_t)acc[r][c][3]};
+                    *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(a.slab) + e) = v;
+                } else {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.slab) + e) = acc[r][c];
+                }
+            }
         }
     }
     WG_MARK(5);  // stores issued
@@ -328,48 +336,27 @@ __global__ __launch_bounds__(NT, (BNW == 256 ? 4 : BM == 128 ? 3 : YMI_WGRAD_WAV
 #endif
 }
 
-// Slab reduction, one launch, deterministic: a 1024-thread workgroup owns 32 consecutive outputs (one 128-byte
-// row piece of every slab) and 32 split lanes; lane j sums splits j, j+32, ... in order, then the 32 lane sums are
-// added in lane order.  dw[co][ci][kh][kw] = sum_s slab[s][co][tap*Cin + ci]  (scatter into OIHW).
-// SL split lanes per output element (8, 16 or 32, chosen so that a lane sums ~8 splits): 1024 / SL consecutive outputs
-// per 1024-thread workgroup, so the grid is one resident round instead of two or three (the kernel is pure latency).
-template <int SL>
-__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real,
-                                                             int cin_real, int ntaps, float* __restrict__ dw) {
-    constexpr int OUTS = 1024 / SL;
-    __shared__ float red[SL][OUTS + 1];
-    const int ol = threadIdx.x % OUTS, lane = threadIdx.x / OUTS;
-    const int64_t e = (int64_t)blockIdx.x * OUTS + ol;  // element of the [CoutP][NG] slab
-    const int64_t elems = (int64_t)CoutP * NG;
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    if (e < elems) {
-        int k = lane;
-        for (; k + 3 * SL < splits; k += 4 * SL) {  // four independent chains in flight
-            s0 += slab[(int64_t)k * elems + e];
-            s1 += slab[(int64_t)(k + SL) * elems + e];
-            s2 += slab[(int64_t)(k + 2 * SL) * elems + e];
-            s3 += slab[(int64_t)(k + 3 * SL) * elems + e];
-        }
-        for (; k < splits; k += SL) s0 += slab[(int64_t)k * elems + e];
-    }
-    red[lane][ol] = (s0 + s1) + (s2 + s3);
-    __syncthreads();
-    if (lane == 0 && e < elems) {
-        float s = 0.f;
-#pragma unroll
-        for (int q = 0; q < SL; ++q) s += red[q][ol];
-        const uint32_t eu = (uint32_t)e;  // < 2^31
-        const int co = (int)(eu / (uint32_t)NG), col = (int)(eu - (uint32_t)co * (uint32_t)NG);
-        const int tap = (int)((uint32_t)col / (uint32_t)Cin), ci = col - tap * Cin;
-        if (co < cout_real && ci < cin_real) dw[((int64_t)co * cin_real + ci) * ntaps + tap] = s;
+// a slab element as float (slabs are float32, or bfloat16 in the bf16 path)
+template <bool BF> __device__ __forceinline__ float slab_at(const void* slab, int64_t i) {
+    if constexpr (BF) return (float)reinterpret_cast<const bf16_t*>(slab)[i];
+    else return reinterpret_cast<const float*>(slab)[i];
+}
+template <bool BF> __device__ __forceinline__ f32x4 slab4_at(const void* slab, int64_t i) {  // i a multiple of 4
+    if constexpr (BF) {
+        const bf16x4 v = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(slab) + i);
+        return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    } else {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(slab) + i);
     }
 }
 
-// few splits (large weight matrices): one thread per output element, coalesced along (tap, ci)
-__global__ void wgrad_reduce_small_kernel(const float* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real, int cin_real,
-                                          int ntaps, float* __restrict__ dw) {
-    // 32-bit index arithmetic (a weight tensor has < 2^31 elements); four independent partial sums keep the split
-    // loads in flight, combined in a fixed order (deterministic)
+// Per-layer slab reduction (ymi_conv2d_bwd_weight, the non-deferred entry point), deterministic: one thread per output element,
+// coalesced along (tap, ci); four independent partial sums keep the split loads in flight, combined in a fixed order.
+// dw[co][ci][kh][kw] = sum_s slab[s][co][tap*Cin + ci]  (scatter into OIHW).
+template <bool BF>
+__global__ void wgrad_reduce_kernel(const void* __restrict__ slab, int splits, int CoutP, int NG, int Cin, int cout_real, int cin_real, int ntaps,
+                                    float* __restrict__ dw) {
+    // 32-bit index arithmetic (a weight tensor has < 2^31 elements)
     const uint32_t total = (uint32_t)cout_real * (uint32_t)ntaps * (uint32_t)cin_real;
     const int64_t sstride = (int64_t)CoutP * NG;
     for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
@@ -377,50 +364,39 @@ __global__ void wgrad_reduce_small_kernel(const float* __restrict__ slab, int sp
         const uint32_t ci = idx - t * (uint32_t)cin_real;
         const uint32_t co = t / (uint32_t)ntaps;
         const uint32_t tap = t - co * (uint32_t)ntaps;
-        const float* p = slab + (int64_t)co * NG + tap * Cin + ci;
+        const int64_t e = (int64_t)co * NG + tap * Cin + ci;
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int k = 0;
         for (; k + 3 < splits; k += 4) {
-            s0 += p[(int64_t)k * sstride];
-            s1 += p[(int64_t)(k + 1) * sstride];
-            s2 += p[(int64_t)(k + 2) * sstride];
-            s3 += p[(int64_t)(k + 3) * sstride];
+            s0 += slab_at<BF>(slab, e + (int64_t)k * sstride);
+            s1 += slab_at<BF>(slab, e + (int64_t)(k + 1) * sstride);
+            s2 += slab_at<BF>(slab, e + (int64_t)(k + 2) * sstride);
+            s3 += slab_at<BF>(slab, e + (int64_t)(k + 3) * sstride);
         }
-        for (; k < splits; ++k) s0 += p[(int64_t)k * sstride];
+        for (; k < splits; ++k) s0 += slab_at<BF>(slab, e + (int64_t)k * sstride);
         dw[((int64_t)co * cin_real + ci) * ntaps + tap] = (s0 + s1) + (s2 + s3);
     }
 }
 
 // All pending slab reductions of a backward pass in ONE launch (ymi_wgrad_reduce_batch): a 256-thread workgroup finds its
 // tensor by binary search over the table's first_block column, then sums `lanes` interleaved split chains per output
-// element in a fixed order (deterministic) and scatters into OIHW - the same arithmetic as the per-layer kernels above,
-// without their 73 launch boundaries (each of those kernels was pure latency: 7-12 us for a few hundred KB).
-__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ymi_wgrad_pending* __restrict__ tab, int n) {
-    __shared__ f32x4 red[256];
-    int lo = 0, hi = n - 1;  // last entry whose first_block <= blockIdx.x
-    while (lo < hi) {
-        const int mid = (lo + hi + 1) >> 1;
-        if (tab[mid].first_block <= (int)blockIdx.x) lo = mid;
-        else hi = mid - 1;
-    }
-    const ymi_wgrad_pending e = tab[lo];
-    // by the end of the backward pass the slabs have left the caches: this kernel streams them from HBM, 16 bytes per
-    // lane and four split chains in flight per lane
+// element in a fixed order (deterministic) and scatters into OIHW.  By the end of the backward pass the slabs have left the
+// caches: this kernel streams them from HBM, 4 elements per lane and load, four split chains in flight per lane.
+template <bool BF> __device__ __forceinline__ void reduce_batch_body(const ymi_wgrad_pending& e, f32x4* red) {
     const int SL = e.lanes, OUTS = 256 / SL;              // OUTS groups of 4 consecutive elements per workgroup
     const int ol = threadIdx.x % OUTS, lane = threadIdx.x / OUTS;
     const int64_t el = ((int64_t)((int)blockIdx.x - e.first_block) * OUTS + ol) * 4;  // first element of this lane's group
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
     if (el < e.elems) {  // elems is a multiple of 8
-        const float* p = e.slab + el;
         int k = lane;
         for (; k + 3 * SL < e.splits; k += 4 * SL) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(p + (int64_t)k * e.elems);
-            const f32x4 b = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + SL) * e.elems);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + 2 * SL) * e.elems);
-            const f32x4 d = *reinterpret_cast<const f32x4*>(p + (int64_t)(k + 3 * SL) * e.elems);
+            const f32x4 a = slab4_at<BF>(e.slab, el + (int64_t)k * e.elems);
+            const f32x4 b = slab4_at<BF>(e.slab, el + (int64_t)(k + SL) * e.elems);
+            const f32x4 c = slab4_at<BF>(e.slab, el + (int64_t)(k + 2 * SL) * e.elems);
+            const f32x4 d = slab4_at<BF>(e.slab, el + (int64_t)(k + 3 * SL) * e.elems);
             s0 += a; s1 += b; s2 += c; s3 += d;
         }
-        for (; k < e.splits; k += SL) s0 += *reinterpret_cast<const f32x4*>(p + (int64_t)k * e.elems);
+        for (; k < e.splits; k += SL) s0 += slab4_at<BF>(e.slab, el + (int64_t)k * e.elems);
     }
     red[lane * OUTS + ol] = (s0 + s1) + (s2 + s3);
     __syncthreads();
@@ -437,8 +413,18 @@ __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ymi_wgrad
         }
     }
 }
-
-constexpr int WG_STAGE_R = 0;
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ymi_wgrad_pending* __restrict__ tab, int n) {
+    __shared__ f32x4 red[256];
+    int lo = 0, hi = n - 1;  // last entry whose first_block <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (tab[mid].first_block <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const ymi_wgrad_pending e = tab[lo];
+    if (e.slab_bf16) reduce_batch_body<true>(e, red);  // (workgroup-uniform)
+    else reduce_batch_body<false>(e, red);
+}
 
 // magic numbers for wg_fast_div
 static void wg_find_divisor(int d, uint32_t* mul, uint32_t* shr) {
@@ -452,28 +438,18 @@ struct WgradPlan {
     int splits, pix_per_split;
     size_t slab_bytes;
 };
-// row-tile choice.  Measured: with the same workgroup target as the 64-row tile the 128-row tile is 5-45 % SLOWER (the
+// row-tile choice.  Measured (round 1): with the same workgroup target as the 64-row tile the 128-row tile is 5-45 % SLOWER (the
 // pixel axis is split twice as often, doubling the slab traffic); with HALF the workgroups (same split count, 16 MFMAs
-// per wave and K step) it is 7-12 % faster on every layer with >= 128 output channels.  YMI_WGRAD_BM=64 disables it.
+// per wave and K step) it is 7-12 % faster on every layer with >= 128 output channels.
 static int wgrad_bm(int64_t coutp, bool bf16) {
-    static const int env = getenv("YMI_WGRAD_BM") ? atoi(getenv("YMI_WGRAD_BM")) : 128;
-    if (!bf16 || env != 128) return 64;
+    if (!bf16) return 64;
     return (coutp >= 128 && coutp % 128 == 0) || coutp >= 256 ? 128 : 64;
 }
-// column-tile choice.  YMI_WGRAD_BN=256 selects the 128x256 tile wherever the (tap, ci) axis has at least 256 columns.  Measured
-// SLOWER although it moves 0.75x the bytes per FLOP (profiles/r02_conv_bench_wgrad256.txt): 1.1-1.66x as four waves with 64x128
-// wave tiles (204 registers), and still 1.17x over the model as eight waves with 64x64 wave tiles (116 registers, two workgroups
-// per CU) - the form that made the same tile win in igemm.  Kept as a knob, off by default.
-static int wgrad_bn(int bm, int64_t ng, bool bf16) {
-    static const int env = getenv("YMI_WGRAD_BN") ? atoi(getenv("YMI_WGRAD_BN")) : 128;
-    return (bf16 && env == 256 && bm == 128 && ng >= 256) ? 256 : WG_BN;
-}
-static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm = WG_BM, int bn = WG_BN) {
-    const int64_t tiles = ((ng + bn - 1) / bn) * ((coutp + bm - 1) / bm);
+static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm, size_t slab_esize) {
+    const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + bm - 1) / bm);
     static const int target64 = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;  // workgroups to aim for (tuning knobs)
     static const int target128 = getenv("YMI_WGRAD_BLOCKS128") ? atoi(getenv("YMI_WGRAD_BLOCKS128")) : 640;
-    static const int target256 = getenv("YMI_WGRAD_BLOCKS256") ? atoi(getenv("YMI_WGRAD_BLOCKS256")) : 512;  // two resident workgroups per CU
-    const int target = bn == 256 ? target256 : bm == 128 ? target128 : target64;
+    const int target = bm == 128 ? target128 : target64;
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t smax = (mpix + 255) / 256;
     if (s > smax) s = smax;
@@ -485,7 +461,7 @@ static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm = WG
     WgradPlan p;
     p.splits = (int)s;
     p.pix_per_split = (int)pps;
-    p.slab_bytes = (size_t)(s + WG_STAGE_R) * coutp * ng * sizeof(float);  // + staging rows of the two-stage reduce
+    p.slab_bytes = ((size_t)s * coutp * ng * slab_esize + 255) / 256 * 256;
     return p;
 }
 
@@ -494,11 +470,9 @@ static int64_t pad_to(int64_t v, int64_t m) { return (v + m - 1) / m * m; }
 extern "C" size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, int64_t cin, int64_t kh, int64_t kw) {
     // upper bound over both dtypes' channel padding (8), plus room for the bias-gradient partials
     const int64_t coutp = pad_to(cout, 8), cinp = pad_to(cin, 8);
-    WgradPlan p = wgrad_plan(m_rows, coutp, kh * kw * cinp, 64);
-    const WgradPlan p128 = wgrad_plan(m_rows, coutp, kh * kw * cinp, 128);  // the 128-row tile splits the pixel axis further
+    WgradPlan p = wgrad_plan(m_rows, coutp, kh * kw * cinp, 64, 4);  // (float32 slabs: the larger of the two dtypes' needs)
+    const WgradPlan p128 = wgrad_plan(m_rows, coutp, kh * kw * cinp, 128, 4);  // the 128-row tile splits the pixel axis further
     if (p128.slab_bytes > p.slab_bytes) p = p128;
-    const WgradPlan p256 = wgrad_plan(m_rows, coutp, kh * kw * cinp, 128, 256);
-    if (p256.slab_bytes > p.slab_bytes) p = p256;
     return p.slab_bytes + (size_t)(2048 * 2 + 1) * coutp * sizeof(float) + 256;
 }
 
@@ -563,16 +537,16 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     YMI_CHECK_ARG(ymi_pixels(x) * x->ld < (1ll << 31) && ymi_pixels(dy) * dy->ld < (1ll << 31), "conv2d_bwd_weight: too large");
     const int64_t mpix = ymi_pixels(dy);
     const int64_t ng = kh * kw * x->c;
-    const int bm = wgrad_bm(dy->c, x->dtype == YMI_BF16);
-    const int bn = wgrad_bn(bm, ng, x->dtype == YMI_BF16);
-    WgradPlan p = wgrad_plan(mpix, dy->c, ng, bm, bn);
+    const bool bf16 = x->dtype == YMI_BF16;
+    const int bm = wgrad_bm(dy->c, bf16), bn = WG_BN;
+    WgradPlan p = wgrad_plan(mpix, dy->c, ng, bm, bf16 ? 2 : 4);
     size_t need = p.slab_bytes + (dbias ? (size_t)(2048 * 2 + 1) * dy->c * sizeof(float) : 0);
     if (workspace_bytes < need) {
         ymi_set_error("conv2d_bwd_weight: workspace %zu < %zu bytes", workspace_bytes, need);
         return YMI_EWORKSPACE;
     }
     WgradArgs a{};
-    a.x = x->data; a.dy = dy->data; a.slab = reinterpret_cast<float*>(workspace); a.zero = ymi_zero_page();
+    a.x = x->data; a.dy = dy->data; a.slab = workspace; a.slab_bf16 = bf16 ? 1 : 0; a.zero = ymi_zero_page();
     a.ldx = x->ld; a.ldy = dy->ld;
     a.Mpix = (int)mpix; a.H = (int)x->h; a.W = (int)x->w; a.Ho = (int)dy->h; a.Wo = (int)dy->w;
     a.stride = (int)stride; a.pad = (int)pad; a.KW = (int)kw;
@@ -580,8 +554,7 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     wg_find_divisor(a.Wo, &a.wo_mul, &a.wo_shr);
     wg_find_divisor(a.Ho, &a.ho_mul, &a.ho_shr);
     a.nx = (int)((ng + bn - 1) / bn); a.ny = (int)((dy->c + bm - 1) / bm); a.splits = p.splits;
-    static const int xcd_env = getenv("YMI_WGRAD_XCD") ? atoi(getenv("YMI_WGRAD_XCD")) : 1;  // tuning knob
-    a.xcd_map = (xcd_env && p.splits >= 8) ? 1 : 0;
+    a.xcd_map = p.splits >= 8 ? 1 : 0;  // (all tiles of a pixel split on one XCD: 275 -> 105 MB of HBM reads per launch, round 1)
     dim3 grid((unsigned)a.nx, (unsigned)a.ny, (unsigned)p.splits);
     if (a.xcd_map) grid = dim3((unsigned)(8 * ((p.splits + 7) / 8) * a.nx * a.ny), 1, 1);
     hipStream_t s = (hipStream_t)stream;
@@ -591,22 +564,10 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
         const double bytes = ((double)ymi_pixels(x) * x->c + (double)mpix * dy->c) * es + (double)dy->c * ng * 4.0;
         prof = ymi_prof_start(s, 1, 2.0 * (double)mpix * (double)dy->c * (double)ng, bytes, x->dtype == YMI_BF16 ? 2500.0 : 157.3);
     }
-    if (x->dtype == YMI_BF16) {
-        static const int ns = getenv("YMI_WGRAD_NS") ? atoi(getenv("YMI_WGRAD_NS")) : 2;  // LDS ring depth (tuning knob)
-        const size_t lds = (size_t)ns * (size_t)(WG_BK * (bm + WG_BN) * 2);
-        if (bn == 256) {
-            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128, 256>), grid, dim3(512), (size_t)2 * (WG_BK * (128 + 256) * 2) + WG_STAMP_LDS, s, a);
-        } else if (bm == 128) {
-            hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
-        } else {
-            if (ns > 2) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 3, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<bf16_t, 4, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            }
-            if (ns == 4) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 4, 64>), grid, dim3(256), lds, s, a);
-            else if (ns == 3) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 3, 64>), grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 64>), grid, dim3(256), lds + WG_STAMP_LDS, s, a);
-        }
+    if (bf16) {
+        // two LDS stages (deeper rings measured equal: same bytes in flight per CU)
+        if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
+        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 64>), grid, dim3(256), (size_t)2 * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
     } else {
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -618,20 +579,15 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     if (pending) {  // the slab sum is left to ymi_wgrad_reduce_batch (one launch for every layer of the backward pass)
         const int lanes = p.splits > 128 ? 32 : p.splits > 32 ? 16 : p.splits > 8 ? 8 : 4;
         *pending = ymi_wgrad_pending{a.slab, dw_oihw, elems, p.splits, a.NG, a.Cin, (int32_t)cout_real, (int32_t)cin_real, (int32_t)(kh * kw), lanes, 0,
-                                     (int32_t)((elems / 4 + 256 / lanes - 1) / (256 / lanes))};
-    } else if (p.splits > 32) {
-#define YMI_WRED(SL) hipLaunchKernelGGL(wgrad_reduce_kernel<SL>, dim3((unsigned)((elems + 1024 / SL - 1) / (1024 / SL))), dim3(1024), 0, s, (const float*)a.slab, \
-                                        p.splits, a.CoutP, a.NG, a.Cin, (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw)
-        if (p.splits <= 64) YMI_WRED(8);
-        else if (p.splits <= 128) YMI_WRED(16);
-        else YMI_WRED(32);
-#undef YMI_WRED
+                                     (int32_t)((elems / 4 + 256 / lanes - 1) / (256 / lanes)), a.slab_bf16};
     } else {
         const int64_t total = cout_real * kh * kw * cin_real;
         int64_t gb = (total + 255) / 256;
         if (gb > 2048) gb = 2048;
-        hipLaunchKernelGGL(wgrad_reduce_small_kernel, dim3((unsigned)gb), dim3(256), 0, s, (const float*)a.slab, p.splits, a.CoutP, a.NG, a.Cin,
-                           (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
+        if (bf16) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3((unsigned)gb), dim3(256), 0, s, (const void*)a.slab, p.splits, a.CoutP, a.NG, a.Cin,
+                                     (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
+        else hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3((unsigned)gb), dim3(256), 0, s, (const void*)a.slab, p.splits, a.CoutP, a.NG, a.Cin,
+                                (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
     }
     YMI_CHECK_LAUNCH("wgrad_reduce");
     if (dbias) {

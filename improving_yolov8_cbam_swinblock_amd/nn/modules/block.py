@@ -42,8 +42,6 @@ class Bottleneck(nn.Module):
         if fused_add and self.training and ops.join_of(xi) is None:
             ops.mark_join(xi, 2)  # consumers of x here: cv1 and the shortcut; their gradient sum forms in cv1's data-gradient epilogue
         h = self.cv1(xi)
-        if self.training:
-            ops.mark_sole(h)  # h feeds cv2 only: cv2's data gradient may carry the reduce pass of cv1's BatchNorm backward
         if fused_add or not self.add:
             return self.cv2(h, residual=xi if self.add else None, out=out)
         return ops.add_residual(self.cv2(h), x, out)

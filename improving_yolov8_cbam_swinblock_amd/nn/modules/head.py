@@ -67,13 +67,10 @@ class Detect(nn.Module):
         self.dfl = DFL(self.reg_max) if self.reg_max > 1 else nn.Identity()
 
     def _branch(self, seq, xi):
-        """Conv -> Conv -> biased 1x1 (head.py:45-59); each intermediate map has exactly one consumer, so in training the next
-        convolution's data gradient carries the reduce pass of the previous block's BatchNorm backward (ops.mark_sole)."""
+        """Conv -> Conv -> biased 1x1 (head.py:45-59)."""
         h = xi
-        for j, m in enumerate(seq):
+        for m in seq:
             h = m(h)
-            if self.training and j + 1 < len(seq):
-                ops.mark_sole(h)
         return h
 
     def forward(self, x):

@@ -164,8 +164,6 @@ class BaseModel(nn.Module):
                     # only on the loss path, where every Detect input is known to receive a gradient: a join waits for ALL
                     # its consumers, and a caller of model(img) may back-propagate through some of the outputs only
                     ops.mark_join(x, plan["consumers"].get(m.i, 1))
-                    if m.i in plan["single"]:
-                        ops.mark_sole(x)  # one consumer, a convolution: its data gradient is the whole gradient of x
                 y.append(x if m.i in self.save else None)
         return x
 
@@ -197,15 +195,7 @@ class BaseModel(nn.Module):
                     if j >= 0 and j not in slot and isinstance(self.model[j], slot_ok) and off % 8 == 0 and c % 8 == 0:
                         slot[j] = (m.i, off, total)
                     off += c
-        # layers read by exactly one later layer whose first operation is a convolution on that very tensor
-        conv_first = (Conv, C2f, SPPF)
-        readers = {}
-        for m in self.model:
-            for j in srcs[m.i]:
-                if j >= 0:
-                    readers.setdefault(j, []).append(m)
-        single = {j for j, ms in readers.items() if len(ms) == 1 and isinstance(ms[0], conv_first) and isinstance(ms[0].f, int) and j not in slot}
-        plan = self._plan = {"slot": slot, "consumers": {j: c for j, c in consumers.items() if c > 1 and ok[j]}, "single": single}
+        plan = self._plan = {"slot": slot, "consumers": {j: c for j, c in consumers.items() if c > 1 and ok[j]}}
         return plan
 
     def _begin_weight_arena(self, x):

@@ -461,50 +461,6 @@ def join_of(t):
     return getattr(t, "_ymi_join", None) if torch.is_grad_enabled() else None
 
 
-class BnProducer:
-    """what a consumer convolution needs to fold the reduce pass of a Conv-BN-act block's BatchNorm backward into its own
-    data-gradient epilogue (ymi_conv2d_bwd_data_bn).  Attached to the block's OUTPUT tensor; filled by the block's forward;
-    `fused` is set by the consumer's backward - (partials, rows) - and consumed by the block's backward."""
-
-    __slots__ = ("raw", "gamma", "beta", "mean", "inv", "act", "fused")
-
-    def __init__(self):
-        self.raw = self.gamma = self.beta = self.mean = self.inv = None
-        self.act = ACT_NONE
-        self.fused = None
-
-
-def mark_sole(t):
-    """the caller (a module, or the layer graph) states that tensor t has exactly ONE consumer and that it is one of this
-    package's convolutions: its data gradient is then the complete gradient of t, and may come pre-multiplied (BnProducer)."""
-    if torch.is_grad_enabled() and t.requires_grad:
-        t._ymi_sole = True
-    return t
-
-
-def bn_producer_of(t):
-    """the BnProducer of t if a consumer may use it: t has one consumer (mark_sole) or a GradJoin (then only the consumer
-    that arrives last sees the complete gradient and fuses)."""
-    if not torch.is_grad_enabled() or not _bn_fuse["on"]:
-        return None
-    prod = getattr(t, "_ymi_bn", None)
-    if prod is None or not (getattr(t, "_ymi_sole", False) or getattr(t, "_ymi_join", None) is not None):
-        return None
-    return prod
-
-
-# Off by default: parity-green, but measured SLOWER (15.08 vs 14.96 ms/step on the same box, profiles/r02_bn_bwd_fuse.txt): the
-# reduce pass is ~20 VALU operations per element that a streaming kernel hides under its HBM time, while in a GEMM epilogue
-# they are serial work of a workgroup at two-per-CU occupancy (as much as the whole K loop of a 3x3 layer with 64 channels).
-# YMI_BN_BWD_FUSE=1 (or ops.set_bn_bwd_fuse(True)) enables it.
-_bn_fuse = {"on": os.environ.get("YMI_BN_BWD_FUSE", "0") == "1"}
-
-
-def set_bn_bwd_fuse(flag):
-    """fold the reduce pass of a Conv-BN-act block's BatchNorm backward into the consumer's data-gradient epilogue (BnProducer)."""
-    _bn_fuse["on"] = bool(flag)
-
-
 def _accumulate(total, adds):
     """total += each addend (explicit launches: the fall-back of consumers without a fusing kernel); total is private."""
     for a in adds:
@@ -561,42 +517,9 @@ def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None):
     return dx
 
 
-def _dgrad_bn(dy, weight4, k, in_shape, dtype, adds, prod):
-    """stride-1 data gradient whose result is the complete gradient of a Conv-BN-act block's output: returns
-    u = gradient * act'(BN(raw)) and leaves the block's BatchNorm partial sums in prod.fused (ymi_conv2d_bwd_data_bn)."""
-    n, cp, h, w = in_shape
-    ty = as_ymi(dy)
-    wd = pack_conv_dgrad(weight4, ty.c, 1, dtype)
-    dx = empty_nhwc(n, cp, h, w, dtype, dy.device)
-    fa = _prep_adds(adds, dtype, True)
-    rows_cap = (n * h * w + 63) // 64
-    partials = torch.empty(rows_cap * 2 * cp, dtype=torch.float32, device=dy.device)
-    rows = ctypes.c_int64(0)
-    check(
-        L().ymi_conv2d_bwd_data_bn(_byref(ty), ptr(wd), cp, k, k, _byref(as_ymi(fa[0])) if len(fa) > 0 else None, _byref(as_ymi(fa[1])) if len(fa) > 1 else None,
-                                   _byref(as_ymi(prod.raw)), ptr(prod.gamma), ptr(prod.beta), ptr(prod.mean), ptr(prod.inv), prod.act, ptr(partials),
-                                   partials.numel(), ctypes.byref(rows), _byref(as_ymi(dx)), stream_ptr()),
-        "conv2d_bwd_data_bn",
-    )
-    prod.fused = (partials, int(rows.value))
-    return dx
-
-
-def _bn_fusable(prod, adds, weight4, stride, in_shape, dtype):
-    if prod is None or adds is None or len(adds) > 2 or stride != 1 or prod.fused is not None:
-        return False
-    n, cp, h, w = in_shape
-    epc = 8 if dtype == torch.bfloat16 else 4
-    return cp == weight4.shape[1] and cp % epc == 0 and tuple(prod.raw.shape) == (n, cp, h, w) and prod.raw.dtype == dtype
-
-
-def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype, prod=None):
-    """data gradient of a consumer of a (possibly joined) tensor: deposits (and returns None) unless it is the last consumer.
-    prod: the BnProducer of the input tensor - if this call yields the COMPLETE gradient of that tensor (no join, or last
-    arrival) it returns the gradient already multiplied by the producer's act' and leaves its BatchNorm partial sums."""
+def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype):
+    """data gradient of a consumer of a (possibly joined) tensor: deposits (and returns None) unless it is the last consumer."""
     adds = join.arrive() if join is not None else []
-    if _bn_fusable(prod, adds, weight4, stride, in_shape, dtype):
-        return _dgrad_bn(dy, weight4, k, in_shape, dtype, adds, prod)
     dx = _dgrad(dy, weight4, k, stride, in_shape, dtype, adds)
     if adds is None:
         join.deposit(dx)
@@ -640,8 +563,7 @@ class _ConvBnAct(torch.autograd.Function):
     (+ Bottleneck add, nn/modules/block.py:488)."""
 
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum, act, residual, slot=None, join=None, res_join=None,
-                prod_out=None, prod_in=None):
+    def forward(ctx, x, weight, gamma, beta, running_mean, running_var, stride, eps, momentum, act, residual, slot=None, join=None, res_join=None):
         dtype = x.dtype
         o, i, k, _ = weight.shape
         n, cp, h, w = x.shape
@@ -666,9 +588,6 @@ class _ConvBnAct(torch.autograd.Function):
         ctx.save_for_backward(x, weight, gamma, beta, raw, stats)
         ctx.cfg = (stride, act, i, residual is not None)
         ctx.joins = (join, res_join)
-        if prod_out is not None:  # (no residual: a hand-through needs the plain output gradient)
-            prod_out.raw, prod_out.gamma, prod_out.beta, prod_out.mean, prod_out.inv, prod_out.act = raw, gamma, beta, stats[0], stats[1], act
-        ctx.prods = (prod_out, prod_in)
         return out
 
     @staticmethod
@@ -683,33 +602,21 @@ class _ConvBnAct(torch.autograd.Function):
         # two separate tensors: AccumulateGrad adopts them as .grad without a clone (views would be copied)
         dgamma = torch.empty(o, dtype=torch.float32, device=dev)
         dbeta = torch.empty(o, dtype=torch.float32, device=dev)
-        prod_out, prod_in = ctx.prods
-        if prod_out is not None and prod_out.fused is not None:
-            # the consumer's data gradient already multiplied by act'(BN(raw)) and left the partial sums: no reduce pass
-            partials, rows = prod_out.fused
-            prod_out.fused = None
-            ws = workspace(5 * o * 4 + 256, dev, "bnbwd5")
-            check(
-                L().ymi_bn_act_bwd_from_partials(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(beta), ptr(partials),
-                                                 rows, _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
-                "bn_act_bwd_from_partials",
-            )
-        else:
-            ws = workspace(2048 * 2 * o * 4 + 256, dev, "bnbwd")
-            check(
-                L().ymi_bn_act_bwd(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(beta), act,
-                                   _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
-                "bn_act_bwd",
-            )
+        ws = workspace(2048 * 2 * o * 4 + 256, dev, "bnbwd")
+        check(
+            L().ymi_bn_act_bwd(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(beta), act,
+                               _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
+            "bn_act_bwd",
+        )
         join, res_join = ctx.joins
         # the residual hand-through first: when x is both the input and the residual (Bottleneck shortcut), the data
         # gradient below is then the join's last consumer and adds `dout` in its epilogue
         dres = _join_plain(res_join, dout) if (has_res and ctx.needs_input_grad[10]) else None
         dx = None
         if ctx.needs_input_grad[0]:
-            dx = _dgrad_joined(join, draw, weight, k, stride, x.shape, dtype, prod_in)
+            dx = _dgrad_joined(join, draw, weight, k, stride, x.shape, dtype)
         dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False, (weight,))
-        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None, None, None
+        return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
 
 
 def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
@@ -721,12 +628,8 @@ def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
         # the backward kernels (BatchNorm backward, data / weight gradient GEMMs) read the output gradient in 16-byte chunks
         raise NotImplementedError(f"training a Conv with {weight.shape[0]} output channels in {x.dtype}: the backward kernels need channel counts in "
                                   f"whole 16-byte chunks (multiples of {chunk_elems(x.dtype)}); every standard YOLOv8 width is - use float32 for this width")
-    grad = torch.is_grad_enabled() and _bn_fuse["on"]
-    prod_out = BnProducer() if (grad and residual is None) else None
     out = _ConvBnAct.apply(x, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, int(stride), float(bn.eps), float(bn.momentum), int(act), residual, slot,
-                           join_of(x), join_of(residual) if residual is not None else None, prod_out, bn_producer_of(x) if grad else None)
-    if prod_out is not None and out.requires_grad:
-        out._ymi_bn = prod_out
+                           join_of(x), join_of(residual) if residual is not None else None)
     if bn.num_batches_tracked is not None:
         if _deferred_counters is not None:
             _deferred_counters.append(bn.num_batches_tracked)
@@ -763,7 +666,7 @@ class _ConvAffineAct(torch.autograd.Function):
     (head.py:45-59) and every nn.Linear of SwinBlock (swin_block.py:29-35) with k = 1."""
 
     @staticmethod
-    def forward(ctx, x, weight, scale, bias, stride, act, residual, cout_pad, join=None, res_join=None, prod_in=None):
+    def forward(ctx, x, weight, scale, bias, stride, act, residual, cout_pad, join=None, res_join=None):
         dtype = x.dtype
         w4 = _as4d(weight)
         o, i, k, _ = w4.shape
@@ -794,7 +697,6 @@ class _ConvAffineAct(torch.autograd.Function):
         ctx.bias_param = bias if (bias is not None and bias.requires_grad) else None  # (a leaf parameter: no cycle)
         ctx.cfg = (stride, i, bias is not None, residual is not None, cout_pad)
         ctx.joins = (join, res_join)
-        ctx.prod_in = prod_in
         return y
 
     @staticmethod
@@ -814,7 +716,7 @@ class _ConvAffineAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if x.dim() == 4:
-                dx = _dgrad_joined(join, dy, w4, k, stride, x.shape, dtype, ctx.prod_in)
+                dx = _dgrad_joined(join, dy, w4, k, stride, x.shape, dtype)
             else:
                 adds = join.arrive() if join is not None else []
                 ty = as_ymi(dy)
@@ -831,15 +733,14 @@ class _ConvAffineAct(torch.autograd.Function):
                     dx = None
         dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias, (weight, ctx.bias_param))
         dw = dw.view(weight.shape)
-        return dx, dw, None, db, None, None, dres, None, None, None, None
+        return dx, dw, None, db, None, None, dres, None, None, None
 
 
 def conv_affine_act(x, weight, scale=None, bias=None, stride=1, act=ACT_NONE, residual=None, pad_out=False):
     w4 = _as4d(weight)
     o = w4.shape[0]
     cout_pad = round_up(o, chunk_elems(x.dtype)) if pad_out else o
-    y = _ConvAffineAct.apply(x, weight, scale, bias, int(stride), int(act), residual, cout_pad, join_of(x), join_of(residual) if residual is not None else None,
-                             bn_producer_of(x) if x.dim() == 4 else None)
+    y = _ConvAffineAct.apply(x, weight, scale, bias, int(stride), int(act), residual, cout_pad, join_of(x), join_of(residual) if residual is not None else None)
     if cout_pad != o:
         y = y[:, :o]
     return y

@@ -165,13 +165,14 @@ size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, int64_t cin
  * The caller keeps `workspace` (the slabs) alive until that launch.  One reduce launch then serves every layer of a
  * backward pass (the 73 per-layer reduce launches of YOLOv8s were pure latency). */
 typedef struct ymi_wgrad_pending {
-    const float* slab;   /* [splits][elems] */
+    const void* slab;    /* [splits][elems], float32 or (slab_bf16) bfloat16 first-level partials */
     float* dw;           /* OIHW destination */
     int64_t elems;       /* padded Cout * (taps * padded Cin) */
     int32_t splits, ng, cin, cout_real, cin_real, ntaps;
     int32_t lanes;       /* interleaved split chains per output element (4, 8, 16 or 32) */
     int32_t first_block; /* set by ymi_wgrad_reduce_batch */
     int32_t blocks;      /* workgroups this record needs: ceil(elems / 4 / (256 / lanes)) */
+    int32_t slab_bf16;   /* 1: the slabs hold bfloat16 (the bf16 path), 0: float32 (parity mode) */
 } ymi_wgrad_pending;
 int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
                                    int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
@@ -304,22 +305,6 @@ int ymi_opt_grad_norm(const ymi_opt_entry* table, const int32_t* chunk_map, int3
  * ema = d*ema + (1-d)*p.  host_grads == NULL: EMA-only pass over the given tensors (buffers, frozen parameters). */
 int ymi_opt_update(const ymi_opt_entry* table, const int32_t* chunk_map, int32_t first_tensor, int32_t n_tensors, int64_t n_chunks,
                    const float* const* host_grads, const float* hyper, const void* state, void* stream);
-
-/* BatchNorm backward with its reduce pass folded into the data gradient that produces the block's output gradient.
- * Reference: the autograd backward of Conv.forward (nn/modules/conv.py:69-79: act(bn(conv(x)))) followed by the consumer's conv.
- * ymi_conv2d_bwd_data_bn: stride-1 data gradient of the CONSUMER convolution; dx receives
- *   u = (conv_transpose(dy, w) + add1 + add2) * act'(BN(bn_raw))   instead of the plain gradient, and partials[rows][2][cin] the
- *   per-workgroup sums of u and u * x^ (x^ = (bn_raw - mean) * invstd); *rows_out = rows written (host value);
- *   partials must hold ceil(pixels / 64) * 2 * cin floats.  16-byte-aligned rows of dx and bn_raw.
- * ymi_bn_act_bwd_from_partials: the producer block's BN backward from u and those partials: dgamma, dbeta and
- *   draw = gamma * invstd * (u - mean(u) - x^ * mean(u * x^)); workspace: 5 * C floats. */
-int ymi_conv2d_bwd_data_bn(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, const ymi_tensor* add1,
-                           const ymi_tensor* add2, const ymi_tensor* bn_raw, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
-                           const float* bn_invstd, int32_t bn_act, float* partials, int64_t partial_floats, int64_t* rows_out,
-                           const ymi_tensor* dx, void* stream);
-int ymi_bn_act_bwd_from_partials(const ymi_tensor* u, const ymi_tensor* raw, const float* gamma, const float* save_mean, const float* save_invstd,
-                                 const float* beta, const float* partials, int64_t rows, const ymi_tensor* draw, float* dgamma, float* dbeta,
-                                 void* workspace, size_t workspace_bytes, void* stream);
 
 /* SwinBlock MLP: Linear(C,4C) -> exact GELU -> Linear(4C,C) (+ skip).  Reference: ultralytics/nn/modules/swin_block.py:33 (definition)
  * and :53 (`x = x + self.mlp(self.norm2(x))`).  Token matrices are ymi_tensors with n = h = 1, w = tokens.

@@ -25,6 +25,11 @@ pytestmark = pytest.mark.gpu
 # kernel) or per key tile against the running maximum (tiled kernel) where the oracle rounds softmax's output (measured
 # 1e-3 / 2.7e-3 forward, up to 3.9e-3 on gradients).
 CONV_BOUND = 1e-3
+# Weight gradients: the split-K partial sums (one per pixel split, a float32 sum over >= 256 pixels) leave wgrad_kernel as
+# bfloat16 slabs and are summed in float32 (csrc/wgrad.hip, round 3: half the slab traffic); the oracle has no such storage
+# point.  One rounding of a partial is 1.1e-3 of ITS magnitude; measured on the sum: 1.7e-3 with a handful of splits (these
+# small cases), less with the 28-85 splits of the bs-32 layers.  float32 parity mode keeps float32 slabs.
+WGRAD_BOUND = 4e-3
 FWD_BOUND = 4e-3
 GRAD_BOUND = 1e-2
 
@@ -90,7 +95,7 @@ def test_conv_block_bf16_vs_matched_oracle(cin, cout, k, s, hw):
     for a, b, n in zip(gg, go, ["x", "w", "gamma", "beta"]):
         errs[n] = rel(a, q(b) if n == "x" else b)   # the product stores the input gradient in bf16; the oracle's leaf gradient is not a stored tensor
     print(f"\n[matched conv {cin}->{cout} k{k} s{s} {hw}] " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()))
-    assert all(e <= CONV_BOUND for e in errs.values()), errs
+    assert all(e <= (WGRAD_BOUND if n == "w" else CONV_BOUND) for n, e in errs.items()), errs
 
 
 def _bn_defaults(m, randomize=False):

@@ -241,7 +241,7 @@ def test_config5_yolov8m_swin384_bs16_1280_train_step_properties():
     missing = [n for n, p in named if p.grad is None]
     assert missing == [], missing
     gn = torch.stack([p.grad.float().norm() for _, p in named])
-    assert len(named) > 300 and bool(torch.isfinite(gn).all()) and float(gn.max()) > 0
+    assert len(named) > 250 and bool(torch.isfinite(gn).all()) and float(gn.max()) > 0
     peak = torch.cuda.max_memory_allocated() / 2**30
     print(f"\n[cfg5 bs16 1280 bf16] loss items {[round(float(v), 4) for v in items]}, {len(named)} gradients finite, peak device memory {peak:.1f} GiB")
     assert peak < 200

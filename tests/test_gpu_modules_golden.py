@@ -385,43 +385,3 @@ def test_weight_arena_pack_equals_per_call_pack():
                 assert torch.equal(d, rd), ("dgrad", o, i, k, s)
         finally:
             ops.set_weight_arena(None)
-
-
-@pytest.mark.gpu
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
-def test_bn_backward_folded_into_data_gradient_matches_separate_passes(dtype):
-    """ymi_conv2d_bwd_data_bn + ymi_bn_act_bwd_from_partials (ops.set_bn_bwd_fuse: the consumer's data gradient multiplies by
-    act'(BN(raw)) and emits the BatchNorm partial sums) against the separate reduce pass, on the two places the model uses
-    it: C2f's Bottlenecks (cv1 -> cv2, with the shortcut join) and Detect's Conv -> Conv -> 1x1 branches.
-    f32: same arithmetic up to summation order (1e-5); bf16: the folded path rounds dy*act' once more (2e-2 relative L2)."""
-    from improving_yolov8_cbam_swinblock_amd import ops
-    from improving_yolov8_cbam_swinblock_amd.nn.modules import C2f, Detect
-
-    dev = torch.device("cuda", 0)
-
-    def run(mod, xs, fuse):
-        ops.set_bn_bwd_fuse(fuse)
-        try:
-            for p in mod.parameters():
-                p.grad = None
-            ins = [x.clone().requires_grad_(True) for x in xs]
-            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
-                out = mod(ins[0]) if len(ins) == 1 else mod(ins)
-            outs = out if isinstance(out, (list, tuple)) else [out]
-            loss = sum((o.float() * torch.linspace(-1, 1, o.numel(), device=dev).view_as(o)).sum() for o in outs)
-            loss.backward()
-            return [i.grad.detach().float().clone() for i in ins] + [p.grad.detach().float().clone() for p in mod.parameters() if p.grad is not None]
-        finally:
-            ops.set_bn_bwd_fuse(False)
-
-    torch.manual_seed(5)
-    tol = 1e-5 if dtype == torch.float32 else 2e-2
-    c2f = C2f(64, 64, n=2, shortcut=True).to(dev).train()
-    det = Detect(nc=3, ch=(64, 128)).to(dev).train()
-    cases = [(c2f, [torch.randn(2, 64, 24, 24, device=dev)]), (det, [torch.randn(2, 64, 16, 16, device=dev), torch.randn(2, 128, 8, 8, device=dev)])]
-    for mod, xs in cases:
-        a = run(mod, xs, False)
-        b = run(mod, xs, True)
-        assert len(a) == len(b)
-        for u, v in zip(a, b):
-            assert float((v - u).norm() / u.norm().clamp(min=1e-9)) < tol
