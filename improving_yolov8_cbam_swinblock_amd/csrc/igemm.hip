@@ -480,7 +480,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 // which both halves finished reading at least one phase earlier.
 // (Round-2 variants that measured slower - wave specialisation, a lockstep 256x128 tile, ring depths 1 / 3, pieces interleaved
 // with the MFMAs, LDS-resident 3x3 input rows in linear pixel order, BatchNorm-backward sums in the data-gradient epilogue -
-// were removed in round 3; their tables are profiles/r02_conv_bench_*.txt and profiles/r02_bn_bwd_fuse.txt, the code is in git.)
+// were removed in round 3; their tables are profiles/r02_conv_bench_*.txt and profiles/r02_bn_bwd_fuse.txt, the code is in git.
+// Round 3 measured two more, parity-green and removed again:
+//  * the LDS-resident 3x3 kernel rebuilt in a padded-linear pixel order (one zero column per image row, one zero row per image: a
+//    tap is a constant row shift, no masks; image double-buffered over 32-channel chunks; 2.2x fewer operand bytes): no longer
+//    bound by bytes, yet 0-9 % on the 80x80 layers and slower wherever 256-row tiles leave fewer workgroups than CUs
+//    (profiles/r03_conv_bench_dconv3.txt);
+//  * a 200-row tile stride for this ping-pong form (this model's maps have 25 * 2^k pixels, so power-of-two tiles give 400 / 800 /
+//    1,600 workgroups for 512 slots; 200-row tiles give 256 / 512 / 1,024): 3-7 % on some 80x80 layers in isolation
+//    (profiles/r03_conv_bench_stride200.txt), 13.98 against 13.97 ms on the whole step.
+// Both K loops sit at ~58 % MFMA-busy; what separates a layer from that figure is its grid against 512 slots (tools/quant_probe.sh,
+// profiles/r03_tile_count_probe.txt: 400 tiles of 128x128 take as long as 512) and the prologue / epilogue of a 1.5-round grid.)
 template <typename T, int BM, int BN, int WM, int WN, int NS, int CPR, bool FAST, bool STATS, int NTHR = 256, bool PP = false>
 __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     constexpr int CH = ElemTraits<T>::CH;

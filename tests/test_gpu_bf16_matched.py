@@ -56,7 +56,10 @@ def q(x):
                                              (64, 64, 3, 2, 21), (64, 128, 3, 2, 37),
                                              # >= 300 tiles of 256x128: the ping-pong form of igemm_kernel, forward and data gradient, ragged last
                                              # tile; 1x1; the four parity classes of a stride-2 data gradient in one launch
-                                             (128, 128, 3, 1, 141), (256, 256, 1, 1, 100), (128, 256, 3, 2, 200)])
+                                             (128, 128, 3, 1, 141), (256, 256, 1, 1, 100), (128, 256, 3, 2, 200),
+                                             # more 3x3 stride-1 shapes: two column blocks, 64-column tiles, odd map sizes, tiles that straddle images
+                                             # (this set also pinned round 3's LDS-resident 3x3 kernel, see profiles/r03_conv_bench_dconv3.txt)
+                                             (128, 128, 3, 1, 80), (256, 256, 3, 1, 20), (128, 64, 3, 1, 40), (64, 128, 3, 1, 23), (32, 64, 3, 1, 61)])
 def test_conv_block_bf16_vs_matched_oracle(cin, cout, k, s, hw):
     """Conv (conv -> train-mode BatchNorm -> SiLU) in bf16: igemm_kernel<bf16> with the statistics epilogue, the affine + SiLU
     kernel, BatchNorm backward, the data-gradient GEMM and wgrad_kernel, against the oracle on identical bf16-valued operands."""

@@ -89,6 +89,7 @@ def main():
     ap.add_argument("--batch", type=int, default=32)
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
+    ap.add_argument("--shape", action="append", default=[], help="extra shape 'name,cin,cout,k,stride,H' (square map; replaces the model's list)")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DYMI_STAMPS) only: print the s_memtime stamps of one workgroup's K steps")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -96,7 +97,13 @@ def main():
     L = _lib.lib()
     tot = {"fwd": 0.0, "dgrad": 0.0, "wgrad": 0.0}
     print(f"{'shape':28s} {'M':>9s} {'GF':>7s} | {'fwd us':>8s} {'TF':>6s} | {'dgrad us':>8s} {'TF':>6s} | {'wgrad us':>8s} {'TF':>6s}")
-    for name, cin, cout, k, s, h, count in SHAPES:
+    shapes = SHAPES
+    if args.shape:
+        shapes = []
+        for spec in args.shape:
+            nm, cin_, cout_, k_, s_, h_ = spec.split(",")
+            shapes.append((nm, int(cin_), int(cout_), int(k_), int(s_), int(h_), 1))
+    for name, cin, cout, k, s, h, count in shapes:
         if args.only and args.only not in name:
             continue
         w = torch.randn(cout, cin, k, k, device=dev) * 0.05
