@@ -531,8 +531,10 @@ __global__ __launch_bounds__(256) void loss_kernel(LossGeom g, const float* __re
 }
 
 // ---- K8: fixed-order final sums: scal[0] = sum of target scores, loss[k] = sum_k / max(scal[0], 1) ------------
+// out_scale (optional, [6]): loss[k] = raw_k * out_scale[k] and loss[3 + k] = raw_k * out_scale[3 + k] - the criterion's two results
+// (loss * gains * batch for backward, loss * gains for logging: reference loss.py:250-255) without elementwise launches behind this one
 __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict__ tss_part, int n_tss, const float* __restrict__ part, int n_part,
-                                                         float* __restrict__ scal, float* __restrict__ loss) {
+                                                         float* __restrict__ scal, float* __restrict__ loss, const float* __restrict__ out_scale) {
     __shared__ double sh[4][256];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     for (int i = threadIdx.x; i < n_tss; i += 256) acc[3] += (double)tss_part[i];
@@ -555,9 +557,16 @@ __global__ __launch_bounds__(256) void loss_final_kernel(const float* __restrict
         const double tss = sh[3][0];
         const double den = tss > 1.0 ? tss : 1.0;
         scal[0] = (float)tss;
-        loss[0] = (float)(sh[0][0] / den);
-        loss[1] = (float)(sh[1][0] / den);
-        loss[2] = (float)(sh[2][0] / den);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const float raw = (float)(sh[k][0] / den);
+            if (out_scale) {
+                loss[k] = raw * out_scale[k];
+                loss[3 + k] = raw * out_scale[3 + k];
+            } else {
+                loss[k] = raw;
+            }
+        }
     }
 }
 
@@ -648,8 +657,8 @@ extern "C" int ymi_detect_loss_sizes(int64_t batch, int64_t anchors, int64_t max
 }
 
 extern "C" int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const float* targets,
-                                   int64_t max_boxes, int32_t topk, float alpha, float beta, float* loss_out, void* state, size_t state_bytes,
-                                   void* workspace, size_t workspace_bytes, void* stream) {
+                                   int64_t max_boxes, int32_t topk, float alpha, float beta, const float* out_scale, float* loss_out, void* state,
+                                   size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream) {
     LossGeom g;
     int rc = fill_geom(g, nl, box_maps, cls_maps, strides, max_boxes, "detect_loss_fwd");
     if (rc) return rc;
@@ -687,7 +696,7 @@ extern "C" int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const
     hipLaunchKernelGGL(finalize_kernel, agrid, dim3(256), 0, s, g, targets, al, gidx, pa, po, st.tgt, st.wgt, st.lab, tss_part);
     if (bf) hipLaunchKernelGGL((loss_kernel<bf16_t, false>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, nullptr, part);
     else hipLaunchKernelGGL((loss_kernel<float, false>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, nullptr, part);
-    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, tss_part, (int)(agrid.x * agrid.y), part, (int)qblocks, st.scal, loss_out);
+    hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, tss_part, (int)(agrid.x * agrid.y), part, (int)qblocks, st.scal, loss_out, out_scale);
     YMI_CHECK_LAUNCH("detect_loss_fwd");
     return YMI_OK;
 }

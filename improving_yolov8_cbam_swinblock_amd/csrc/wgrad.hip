@@ -591,19 +591,10 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     }
     YMI_CHECK_LAUNCH("wgrad_reduce");
     if (dbias) {
-        // bias gradient: column sums of dy (first cout_real channels are the real ones)
+        // bias gradient: column sums of dy, written straight into the caller's buffer of dy->c floats (the real channels come first)
         float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.slab_bytes);
-        float* sums = part + (size_t)2048 * 2 * dy->c;
-        const bool direct = cout_real == dy->c;  // no channel padding: the sums ARE the bias gradient, no copy
-        int rc = ymi_colsum(dy, direct ? dbias : sums, part, (size_t)2048 * 2 * dy->c * sizeof(float), stream);
+        int rc = ymi_colsum(dy, dbias, part, (size_t)2048 * 2 * dy->c * sizeof(float), stream);
         if (rc) return rc;
-        if (!direct) {  // copy the real channels out
-            hipError_t e = hipMemcpyAsync(dbias, sums, cout_real * sizeof(float), hipMemcpyDeviceToDevice, s);
-            if (e != hipSuccess) {
-                ymi_set_error("conv2d_bwd_weight: dbias copy: %s", hipGetErrorString(e));
-                return YMI_ELAUNCH;
-            }
-        }
     }
     return YMI_OK;
 }

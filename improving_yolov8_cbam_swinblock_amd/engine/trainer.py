@@ -73,6 +73,7 @@ class TrainStep:
         self._static = None
         self._static_items = None
         self._graph_grads = None
+        self._seed = None
 
     def __call__(self, batch):
         if not self.use_graph:
@@ -121,13 +122,16 @@ class TrainStep:
         self.model.train()
         with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
             loss, items = self.model(batch)
-            total = loss.sum() * self.world
         # this step owns its gradients: zero_grad(set_to_none=True) after every update, so AccumulateGrad adopts the tensors
         # the weight-gradient Functions return and nothing reads them before backward() is over - the condition under which
         # their slab sums may be batched into one launch at the end of the pass (ops.deferred_wgrad; parameters that do hold a
         # gradient or a hook - the overlapped DDP schedule - are detected there and reduced at once)
+        # backward of loss.sum() * world (reference trainer.py:386-388, 394) seeded directly with d(total)/d(loss) = world: the
+        # sum, the multiplication and their backward nodes would be five one-element launches
+        if self._seed is None or self._seed.device != loss.device:
+            self._seed = torch.full((3,), float(self.world), dtype=torch.float32, device=loss.device)
         with ops.deferred_wgrad(True), ops.async_wgrad(ASYNC_WGRAD and not self.use_graph):  # joins the side stream on exit
-            total.backward()
+            torch.autograd.backward([loss], [self._seed])
         return items
 
     def _reduce_and_update(self, grads_of=None):

@@ -71,7 +71,7 @@ class C2f(nn.Module):
             slot = lambda j: ops.OutSlot(buf, j * self.c)  # noqa: E731
         t, last = ops.c2f_split(self.cv1(x, out=slot(0)), self.c)  # (both chunks, second chunk): channel slices, no copy
         ys = [t]  # both chunks go into the concat at once: they are adjacent in memory
-        nm = len(self.m)
+        first_join = None
         for j, m in enumerate(self.m):
             # consumers of a Bottleneck's input: its cv1, its shortcut (if any) and - for j >= 1, where the input is the
             # previous Bottleneck's output - the concat; the right half of t reaches the concat through c2f_split instead
@@ -79,10 +79,13 @@ class C2f(nn.Module):
             # with or without the concat buffer - ops.concat is a join-aware consumer either way.  Other widths reach the
             # Bottleneck as padded copies: autograd sums their gradients and nothing is marked.
             if dense:
-                ops.mark_join(last, 1 + int(m.add) + int(j >= 1))
+                ops.mark_join(last, 1 + int(m.add) + int(j >= 1), force=(j == 0))
+                if j == 0:
+                    first_join = ops.join_of(last)
             last = m(last, out=slot(2 + j))
             ys.append(last)
-        return self.cv2(ops.concat(ys, buf), out=out)
+        # the concat's gradient for the right half of t and the first Bottleneck's input gradient are summed in the latter's epilogue
+        return self.cv2(ops.concat(ys, buf, split_join=(first_join, self.c) if first_join is not None else None), out=out)
 
     forward_split = forward
 
@@ -99,5 +102,11 @@ class SPPF(nn.Module):
         self.m = nn.MaxPool2d(kernel_size=k, stride=1, padding=k // 2)  # attribute kept for parity with the reference
 
     def forward(self, x, out=None):
-        y0 = self.cv1(x)
-        return self.cv2(ops.sppf_pool_cat(y0, self.m.kernel_size), out=out)
+        x = ops.to_internal(x)
+        c_ = self.cv1.conv.out_channels
+        cat = None
+        if self.training and hasattr(self.cv1, "bn") and c_ % ops.chunk_elems(x.dtype) == 0:
+            n, _, h, w = x.shape
+            cat = ops.empty_nhwc(n, 4 * c_, h, w, x.dtype, x.device)  # cv1 writes y0 straight into slice 0 of the concat buffer
+        y0 = self.cv1(x, out=ops.OutSlot(cat, 0) if cat is not None else None)
+        return self.cv2(ops.sppf_pool_cat(y0, self.m.kernel_size, cat), out=out)

@@ -250,12 +250,12 @@ def _wgrad(x, dy, cout, cin, k, stride, want_bias, params=()):
         return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, params[0] if params else None)
     dev = x.device
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
-    db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
     ty, tx = as_ymi(dy), as_ymi(x)
+    db = torch.empty(ty.c, dtype=torch.float32, device=dev) if want_bias else None  # (column sums of every channel of dy, padded ones included)
     need = L().ymi_conv2d_bwd_weight_workspace(ty.n * ty.h * ty.w, ty.c, tx.c, k, k)
     ws = workspace(need, dev, "wgrad")
     check(L().ymi_conv2d_bwd_weight(_byref(tx), _byref(ty), cout, cin, k, k, stride, ptr(dw), ptr(db), ptr(ws), ws.numel(), stream_ptr()), "conv2d_bwd_weight")
-    return dw, db
+    return dw, (db[:cout] if want_bias else None)
 
 
 def _adoptable(params):
@@ -409,8 +409,8 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
         _deferred["task"] = task
     dev = x.device
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
-    db = torch.empty(cout, dtype=torch.float32, device=dev) if want_bias else None
     ty, tx = as_ymi(dy), as_ymi(x)
+    db = torch.empty(ty.c, dtype=torch.float32, device=dev) if want_bias else None
     need = L().ymi_conv2d_bwd_weight_workspace(ty.n * ty.h * ty.w, ty.c, tx.c, k, k)
     ws = torch.empty(int(need), dtype=torch.uint8, device=dev)
     rec = _lib.WgradPending()
@@ -419,7 +419,7 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
     _deferred["records"].append(rec)
     _deferred["keep"].append((ws, x, dy))
     _deferred["owners"].append(owner)
-    return dw, db
+    return dw, (db[:cout] if want_bias else None)
 
 
 class GradJoin:
@@ -433,10 +433,13 @@ class GradJoin:
     Reference sites: Bottleneck shortcut (block.py:488), the two Detect branches (head.py:72), neck skip connections
     (yolov8.yaml:760-773), SwinBlock residuals (swin_block.py:52-53), C2f chunk / concat (block.py:302-304)."""
 
-    __slots__ = ("n", "seen", "pending")
+    __slots__ = ("n", "seen", "pending", "out")
 
     def __init__(self, n):
         self.n, self.seen, self.pending = int(n), 0, []
+        # optional: a buffer that already holds one more contribution (set during backward by the producer of that contribution);
+        # the last-arriving data gradient then adds it as an addend AND writes the total there (C2f's chunk: see _C2fSplit)
+        self.out = None
 
     def arrive(self):
         """-> the deposits if the caller is the last consumer (it must return the total), else None (it must deposit)."""
@@ -450,9 +453,10 @@ class GradJoin:
         self.pending.append(g)
 
 
-def mark_join(t, consumers):
-    """attach a GradJoin for `consumers` join-aware consumers to tensor t (training, grad enabled, > 1 consumer)."""
-    if consumers > 1 and torch.is_grad_enabled() and t.requires_grad:
+def mark_join(t, consumers, force=False):
+    """attach a GradJoin for `consumers` join-aware consumers to tensor t (training, grad enabled, > 1 consumer - or `force`:
+    a single consumer whose data gradient should pick up GradJoin.out)."""
+    if (consumers > 1 or force) and torch.is_grad_enabled() and t.requires_grad:
         t._ymi_join = GradJoin(consumers)
     return t
 
@@ -495,14 +499,15 @@ def _prep_adds(adds, dtype, like4d):
     return out
 
 
-def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None):
+def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None):
     """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight (+ up to two addends summed in the GEMM's
-    epilogue, further ones by accumulate launches); zero-padded input channels get zero."""
+    epilogue, further ones by accumulate launches); zero-padded input channels get zero.  out: write the result into this
+    NHWC view (it may be one of the addends: the epilogue reads an addend before it stores the sum)."""
     n, cp, h, w = in_shape
     cin = weight4.shape[1]
     ty = as_ymi(dy)
     wd = pack_conv_dgrad(weight4, ty.c, stride, dtype)
-    dx = empty_nhwc(n, cp, h, w, dtype, dy.device)
+    dx = out if (out is not None and tuple(out.shape) == (n, cp, h, w) and cp == cin) else empty_nhwc(n, cp, h, w, dtype, dy.device)
     dxv = dx
     if cp != cin:
         dx.zero_()
@@ -520,7 +525,14 @@ def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None):
 def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype):
     """data gradient of a consumer of a (possibly joined) tensor: deposits (and returns None) unless it is the last consumer."""
     adds = join.arrive() if join is not None else []
-    dx = _dgrad(dy, weight4, k, stride, in_shape, dtype, adds)
+    out = None
+    if adds is not None and join is not None and join.out is not None:
+        out, join.out = join.out, None
+        if len(adds) < 2 and _dense_ok(out, dtype) and tuple(out.shape) == tuple(in_shape):
+            adds = list(adds) + [out]  # the contribution already in the buffer rides as an addend; the total replaces it
+        else:
+            out = None  # (left for _C2fSplit's own add)
+    dx = _dgrad(dy, weight4, k, stride, in_shape, dtype, adds, out)
     if adds is None:
         join.deposit(dx)
         return None
@@ -675,15 +687,13 @@ class _ConvAffineAct(torch.autograd.Function):
         if x.dim() == 4:
             n, cp, h, w = x.shape
             ho, wo = _conv_out_hw(h, w, k, stride)
+            # (padded channels - an output whose width is not a whole 16-byte chunk, e.g. Detect's class map at nc = 1 - are never
+            # read: every consumer sees the [:, :o] view, and the GRADIENT's padded channels are zeros written by its producer)
             y = empty_nhwc(n, cout_pad, ho, wo, dtype, dev)
             yv = y[:, :o] if cout_pad != o else y
-            if cout_pad != o:
-                y.zero_()
         else:
             y = torch.empty((x.shape[0], cout_pad), dtype=dtype, device=dev)
             yv = y[:, :o] if cout_pad != o else y
-            if cout_pad != o:
-                y.zero_()
         check(
             L().ymi_conv2d_fwd(_byref(as_ymi(x)), ptr(wp), o, k, k, stride, ptr(scale), ptr(bias), act,
                                _byref(as_ymi(residual)) if residual is not None else None, _byref(as_ymi(yv)), None, None, stream_ptr()),
@@ -742,8 +752,44 @@ def conv_affine_act(x, weight, scale=None, bias=None, stride=1, act=ACT_NONE, re
     cout_pad = round_up(o, chunk_elems(x.dtype)) if pad_out else o
     y = _ConvAffineAct.apply(x, weight, scale, bias, int(stride), int(act), residual, cout_pad, join_of(x), join_of(residual) if residual is not None else None)
     if cout_pad != o:
-        y = y[:, :o]
+        y = _ChanSlice.apply(y, o)
     return y
+
+
+class _ChanSlice(torch.autograd.Function):
+    """y[:, :o] of a channel-padded tensor.  Backward: the gradient of the padded tensor with zeros in the padded channels.  When
+    the incoming gradient already IS the [:, :o] view of such a padded buffer (the detection loss writes its class-map gradients
+    that way, pads zeroed) the buffer is handed through; otherwise zeros + copy, as autograd's own slice would do."""
+
+    @staticmethod
+    def forward(ctx, y, o):
+        ctx.shape = tuple(y.shape)
+        return y[:, :o]
+
+    @staticmethod
+    def backward(ctx, g):
+        base = g._base
+        if (base is not None and tuple(base.shape) == ctx.shape and base.dtype == g.dtype and base.data_ptr() == g.data_ptr()
+                and base.stride() == g.stride() and getattr(base, "_ymi_zero_pad", False)):
+            return base, None
+        full = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last) if len(ctx.shape) == 4 \
+            else torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
+        full[:, : g.shape[1]].copy_(g)
+        return full, None
+
+
+def padded_grad_like(t):
+    """a gradient buffer for tensor t: if t is the [:, :c] view of a channel-padded NHWC tensor (pixel stride ld > c), a zeroed
+    buffer of the PADDED shape whose [:, :c] view is returned (see _ChanSlice.backward); else an empty tensor like t."""
+    if t.dim() == 4 and is_nhwc(t):
+        ld = as_ymi(t).ld
+        n, c, h, w = t.shape
+        if ld != c and ld % chunk_elems(t.dtype) == 0 and ld - c < chunk_elems(t.dtype):
+            base = empty_nhwc(n, ld, h, w, t.dtype, t.device)
+            base.zero_()
+            base._ymi_zero_pad = True
+            return base[:, :c]
+    return torch.empty_like(t)
 
 
 def linear(x, weight, bias=None, residual=None):
@@ -874,7 +920,7 @@ class _Concat(torch.autograd.Function):
     """channel concat by strided copies into one NHWC buffer (conv.py:683, block.py:226,304)."""
 
     @staticmethod
-    def forward(ctx, buf, joins, *xs):
+    def forward(ctx, buf, joins, split_join, *xs):
         n, _, h, w = xs[0].shape
         cs = [t.shape[1] for t in xs]
         out = buf if buf is not None else empty_nhwc(n, sum(cs), h, w, xs[0].dtype, xs[0].device)
@@ -888,6 +934,7 @@ class _Concat(torch.autograd.Function):
             off += c
         ctx.cs = cs
         ctx.joins = joins
+        ctx.split_join = split_join
         return out if buf is None else out[:, :]
 
     @staticmethod
@@ -896,12 +943,18 @@ class _Concat(torch.autograd.Function):
         for c, j in zip(ctx.cs, ctx.joins):
             outs.append(_join_plain(j, g[:, off : off + c]))  # inputs with other consumers: the slice is deposited for the last of them
             off += c
-        return (None, None, *outs)
+        if ctx.split_join is not None and outs[0] is not None:
+            # C2f: the right half of the first input is ALSO the first Bottleneck's input.  Tell that tensor's join where this half of
+            # the gradient lies: the Bottleneck's data gradient adds it in its epilogue and writes the sum back in place.
+            join, c0 = ctx.split_join
+            join.out = outs[0][:, c0:]
+        return (None, None, None, *outs)
 
 
-def concat(xs, buf=None):
-    """channel concat; buf: optional pre-allocated NHWC buffer whose slices some inputs already alias (OutSlot)."""
-    return _Concat.apply(buf, tuple(join_of(t) for t in xs), *xs)
+def concat(xs, buf=None, split_join=None):
+    """channel concat; buf: optional pre-allocated NHWC buffer whose slices some inputs already alias (OutSlot).
+    split_join: (GradJoin of the tensor that is the channel slice [c0:] of the FIRST input, c0) - see _Concat.backward."""
+    return _Concat.apply(buf, tuple(join_of(t) for t in xs), split_join, *xs)
 
 
 class _C2fSplit(torch.autograd.Function):
@@ -923,7 +976,9 @@ class _C2fSplit(torch.autograd.Function):
             n, c2, h, w = ctx.shape
             g_full = empty_nhwc(n, c2, h, w, g_right.dtype, g_right.device)
             g_full.zero_()
-        if g_right is not None:
+        if g_right is not None and g_right.data_ptr() == g_full[:, c:].data_ptr() and g_right.stride() == g_full.stride() and g_right.dtype == g_full.dtype:
+            pass  # the first Bottleneck's data gradient already summed into the right half in place (GradJoin.out)
+        elif g_right is not None:
             dt = g_full.dtype
             if not _dense_ok(g_full, dt):
                 g_full = grad_nhwc(g_full, dt)
@@ -979,11 +1034,13 @@ class _SppfPool(torch.autograd.Function):
     """cat[y0, mp(y0), mp(mp(y0)), mp(mp(mp(y0)))] in one buffer: block.py:222-226."""
 
     @staticmethod
-    def forward(ctx, y0, k):
+    def forward(ctx, y0, k, cat=None):
         n, c, h, w = y0.shape
-        cat = empty_nhwc(n, 4 * c, h, w, y0.dtype, y0.device)
+        if cat is None:
+            cat = empty_nhwc(n, 4 * c, h, w, y0.dtype, y0.device)
         sl = [cat[:, i * c : (i + 1) * c] for i in range(4)]
-        check(L().ymi_copy(_byref(as_ymi(y0)), _byref(as_ymi(sl[0])), stream_ptr()), "copy")
+        if not (y0.data_ptr() == sl[0].data_ptr() and y0.stride() == sl[0].stride()):  # (the producer given the slot already wrote it)
+            check(L().ymi_copy(_byref(as_ymi(y0)), _byref(as_ymi(sl[0])), stream_ptr()), "copy")
         check(L().ymi_sppf_pool3_fwd(_byref(as_ymi(y0)), k, _byref(as_ymi(sl[1])), _byref(as_ymi(sl[2])), _byref(as_ymi(sl[3])), stream_ptr()), "sppf_pool3_fwd")
         ctx.save_for_backward(cat)
         ctx.k, ctx.c = k, c
@@ -1003,11 +1060,12 @@ class _SppfPool(torch.autograd.Function):
                                    _byref(as_ymi(d[2])), _byref(as_ymi(d[3])), _byref(as_ymi(d[0])), stream_ptr()),
             "sppf_pool3_bwd",
         )
-        return d[0], None
+        return d[0], None, None
 
 
-def sppf_pool_cat(y0, k):
-    return _SppfPool.apply(y0, int(k))
+def sppf_pool_cat(y0, k, cat=None):
+    """cat: optional concat buffer whose slice 0 y0 already is (SPPF.cv1 wrote it there)."""
+    return _SppfPool.apply(y0, int(k), cat)
 
 
 # ----------------------------------------------------------------------------------------- CBAM
@@ -1209,10 +1267,11 @@ def _map_array(maps):
 
 
 class _DetectLoss(torch.autograd.Function):
-    """(box maps, class maps) -> [3] = (box, cls, dfl) loss sums / max(sum of target scores, 1)."""
+    """(box maps, class maps) -> (loss [3] * scale[:3], items [3] = loss * scale[3:]) with loss = (box, cls, dfl) sums / max(sum of
+    target scores, 1): both results of the criterion (reference loss.py:250-255) leave the last loss kernel, no elementwise launches."""
 
     @staticmethod
-    def forward(ctx, targets, strides, topk, alpha, beta, *maps):
+    def forward(ctx, targets, strides, topk, alpha, beta, scale6, *maps):
         nl = len(maps) // 2
         box, cls = maps[:nl], maps[nl:]
         dev = box[0].device
@@ -1223,35 +1282,38 @@ class _DetectLoss(torch.autograd.Function):
         check(L().ymi_detect_loss_sizes(b, anchors, g, _byref(sb), _byref(wb)), "detect_loss_sizes")
         state = torch.empty(sb.value, dtype=torch.uint8, device=dev)
         ws = workspace(wb.value, dev, "detloss")
-        loss = torch.empty(3, dtype=torch.float32, device=dev)
+        out = torch.empty(6, dtype=torch.float32, device=dev)
         st = (ctypes.c_float * nl)(*[float(s) for s in strides])
         check(
-            L().ymi_detect_loss_fwd(nl, _map_array(box), _map_array(cls), st, ptr(targets), g, int(topk), float(alpha), float(beta), ptr(loss),
+            L().ymi_detect_loss_fwd(nl, _map_array(box), _map_array(cls), st, ptr(targets), g, int(topk), float(alpha), float(beta), ptr(scale6), ptr(out),
                                     ptr(state), state.numel(), ptr(ws), ws.numel(), stream_ptr()),
             "detect_loss_fwd",
         )
-        ctx.save_for_backward(state, *maps)
+        ctx.save_for_backward(state, scale6, *maps)
         ctx.strides = st
-        return loss
+        loss, items = out[:3], out[3:]
+        ctx.mark_non_differentiable(items)
+        return loss, items
 
     @staticmethod
-    def backward(ctx, gl):
-        state, *maps = ctx.saved_tensors
+    def backward(ctx, gl, _gitems):
+        state, scale6, *maps = ctx.saved_tensors
         nl = len(maps) // 2
         box, cls = maps[:nl], maps[nl:]
-        gl = gl.to(torch.float32).contiguous()
+        gl = gl.to(torch.float32) * scale6[:3]  # the kernel differentiates the unscaled sums
         dbox = [torch.empty_like(t) for t in box]
-        dcls = [torch.empty_like(t) for t in cls]
+        dcls = [padded_grad_like(t) for t in cls]
         check(
             L().ymi_detect_loss_bwd(nl, _map_array(box), _map_array(cls), ctx.strides, ptr(state), state.numel(), ptr(gl), _map_array(dbox),
                                     _map_array(dcls), stream_ptr()),
             "detect_loss_bwd",
         )
-        return (None, None, None, None, None, *dbox, *dcls)
+        return (None, None, None, None, None, None, *dbox, *dcls)
 
 
-def detect_loss(box_maps, cls_maps, strides, targets, topk=10, alpha=0.5, beta=6.0):
-    return _DetectLoss.apply(targets, tuple(strides), topk, alpha, beta, *box_maps, *cls_maps)
+def detect_loss(box_maps, cls_maps, strides, targets, scale6, topk=10, alpha=0.5, beta=6.0):
+    """-> (loss [3] * scale6[:3] (differentiable), items [3] = loss * scale6[3:] (detached))."""
+    return _DetectLoss.apply(targets, tuple(strides), topk, alpha, beta, scale6, *box_maps, *cls_maps)
 
 
 def detect_decode(box_maps, cls_maps, strides):

@@ -22,9 +22,10 @@ class SplitPreds:
         self.box, self.cls = box, cls
 
 
-def _dense_nhwc(t):
-    """a dense NHWC copy unless the tensor already is one (differentiable)."""
-    if t.is_contiguous(memory_format=torch.channels_last) and t.data_ptr() % 16 == 0:
+def _nhwc_map(t, box):
+    """the tensor itself when the kernels can read it: NHWC memory (a channel slice of a wider, padded buffer is fine: the kernels
+    take a pixel stride), 16-byte-aligned rows for box maps; else a dense NHWC copy (differentiable)."""
+    if ops.is_nhwc(t) and (not box or (t.data_ptr() % 16 == 0 and (ops.as_ymi(t).ld * t.element_size()) % 16 == 0)):
         return t
     return t.contiguous(memory_format=torch.channels_last)
 
@@ -43,6 +44,7 @@ class v8DetectionLoss:
         self.topk, self.alpha, self.beta = tal_topk, 0.5, 6.0  # reference loss.py:169
         self.gains = torch.tensor([self.hyp.box, self.hyp.cls, self.hyp.dfl], dtype=torch.float, device=self.device)
         self.stride_list = [float(v) for v in det.stride]  # host copy: no device->host reads on the step path
+        self._scales = {}  # batch size -> device [6] = (gains * B, gains)
 
     def max_boxes(self, batch_idx, batch_size):
         """largest number of labels in one image (one device->host read; pass batch["max_boxes"] to avoid it)."""
@@ -59,8 +61,8 @@ class v8DetectionLoss:
             cls = [f[:, self.reg_max * 4 :] for f in feats]
         if not box[0].is_cuda:
             raise RuntimeError("v8DetectionLoss runs in libyolo_mi355 kernels: predictions must be on the MI355X (cuda) device; there is no CPU path")
-        box = [_dense_nhwc(t) for t in box]
-        cls = [_dense_nhwc(t).to(box[0].dtype) for t in cls]
+        box = [_nhwc_map(t, True) for t in box]
+        cls = [_nhwc_map(t if t.dtype == box[0].dtype else t.to(box[0].dtype), False) for t in cls]
         B = box[0].shape[0]
         h, w = box[0].shape[2:]
         s0 = self.stride_list[0]
@@ -69,5 +71,9 @@ class v8DetectionLoss:
             g = self.max_boxes(batch["batch_idx"], B)
         g = max(int(g), 1)  # an all-background batch still needs one (empty) slot per image
         targets = ops.detect_targets(batch["batch_idx"], batch["cls"], batch["bboxes"], B, g, w * s0, h * s0, box[0].device)
-        loss = ops.detect_loss(box, cls, self.stride_list, targets, self.topk, self.alpha, self.beta) * self.gains
-        return loss * B, loss.detach()
+        # both results leave the last loss kernel: loss * gains * B (differentiable) and loss * gains (reference loss.py:250-255)
+        scale = self._scales.get(B)
+        if scale is None:
+            gh = [float(self.hyp.box), float(self.hyp.cls), float(self.hyp.dfl)]
+            scale = self._scales[B] = torch.tensor([g * B for g in gh] + gh, dtype=torch.float32, device=box[0].device)
+        return ops.detect_loss(box, cls, self.stride_list, targets, scale, self.topk, self.alpha, self.beta)

@@ -155,7 +155,7 @@ int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_
 int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
                             const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream);
 /* dw (OIHW f32 [cout_real][cin_real][kh][kw], overwritten) = sum over pixels dy (x) x ; optional
- * dbias[cout_real] = column sums of dy.  x / dy may carry zero-padded channels (x->c >= cin_real,
+ * dbias = column sums of dy: a buffer of dy->c floats (the PADDED channel count), of which the first cout_real are the bias gradient.  x / dy may carry zero-padded channels (x->c >= cin_real,
  * dy->c >= cout_real).  Split-K MFMA GEMM + ordered slab reduce (deterministic); workspace from
  * ymi_conv2d_bwd_weight_workspace. */
 int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
@@ -256,12 +256,16 @@ int ymi_detect_targets(const float* batch_idx, const float* cls, const float* bb
                        float img_w, float img_h, float* out, void* stream);
 /* bytes of the state (kept from forward to backward) and of the scratch workspace */
 int ymi_detect_loss_sizes(int64_t batch, int64_t anchors, int64_t max_boxes, size_t* state_bytes, size_t* workspace_bytes);
-/* loss_out[3] = (box, cls, dfl) sums divided by max(sum of target scores, 1), before the hyper-parameter gains.
+/* raw[3] = (box, cls, dfl) sums divided by max(sum of target scores, 1), before the hyper-parameter gains.
+ * out_scale == NULL: loss_out[3] = raw.  out_scale (device [6]): loss_out[6], loss_out[k] = raw[k] * out_scale[k] and
+ * loss_out[3 + k] = raw[k] * out_scale[3 + k]: the criterion's two results (loss * gains * batch, loss * gains; reference
+ * utils/loss.py:250-255) from this one launch.
  * strides: host array [nl]; targets: device [batch, max_boxes, 5] as written by ymi_detect_targets. */
 int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const float* targets,
-                        int64_t max_boxes, int32_t topk, float alpha, float beta, float* loss_out, void* state, size_t state_bytes,
-                        void* workspace, size_t workspace_bytes, void* stream);
-/* gradients of sum_k grad_loss[k] * loss_out[k] with respect to the maps (grad_loss: device [3]) */
+                        int64_t max_boxes, int32_t topk, float alpha, float beta, const float* out_scale, float* loss_out, void* state,
+                        size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream);
+/* gradients of sum_k grad_loss[k] * raw[k] with respect to the maps (grad_loss: device [3]).  dcls_maps may be channel slices of
+ * wider buffers (ld > c): only the nc class channels are written. */
 int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const void* state,
                         size_t state_bytes, const float* grad_loss, const ymi_tensor* dbox_maps, const ymi_tensor* dcls_maps, void* stream);
 
