@@ -103,6 +103,13 @@ template <> struct Pack<bf16_t, 8> {
 };
 
 // e^x as one v_exp_f32 (2^(x*log2 e)): ~1 ulp, results below 2^-126 flush to zero; no range-reduction code
+// Workgroups are dealt round-robin to the 8 XCDs (flat id & 7), each with its own L2.  Work units that read neighbouring bytes
+// (the 16-byte channel chunks of one 128-byte line, the heads of one token row) should therefore NOT sit on consecutive flat
+// ids: every XCD would fetch the whole line.  xcd_unit() turns the flat workgroup id into a work-unit index such that
+// consecutive UNITS run on one XCD, back to back (a permutation of [0, total) when total % 8 == 0, the identity otherwise).
+__device__ __forceinline__ int xcd_unit(int flat, int total) { return (total & 7) ? flat : (flat & 7) * (total >> 3) + (flat >> 3); }
+__device__ __forceinline__ int flat_block_id() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+
 __device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 // 1 / (1 + e^-x) with v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of the IEEE division sequence
 __device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }

@@ -49,10 +49,13 @@ __global__ __launch_bounds__(256) void sppf_pool3_kernel(PoolArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int r = a.k / 2;
     const int tiles_w = (a.W + a.TW - 1) / a.TW;
-    const int th0 = (blockIdx.x / tiles_w) * a.TH, tw0 = (blockIdx.x % tiles_w) * a.TW;
+    // unit order: channel slab fastest, then tile, then image; consecutive units on one XCD (neighbouring slabs share 128-byte lines)
+    const int unit = xcd_unit(flat_block_id(), gridDim.x * gridDim.y * gridDim.z);
+    const int bslab = unit % gridDim.y, btile = (unit / gridDim.y) % gridDim.x;
+    const int th0 = (btile / tiles_w) * a.TH, tw0 = (btile % tiles_w) * a.TW;
     const int th1 = min(th0 + a.TH, a.H), tw1 = min(tw0 + a.TW, a.W);
-    const int c0 = blockIdx.y * CS;
-    const int n = blockIdx.z;
+    const int c0 = bslab * CS;
+    const int n = unit / (gridDim.x * gridDim.y);
     // staged region = tile + 3r halo, clamped to the image
     const int rh0 = max(th0 - 3 * r, 0), rh1 = min(th1 + 3 * r, a.H);
     const int rw0 = max(tw0 - 3 * r, 0), rw1 = min(tw1 + 3 * r, a.W);
@@ -140,36 +143,9 @@ static bool pool_geometry(int H, int W, int k, int es, int* TH, int* TW, size_t*
     return true;
 }
 
-extern "C" int ymi_sppf_pool3_fwd(const ymi_tensor* y0, int64_t k, const ymi_tensor* y1, const ymi_tensor* y2, const ymi_tensor* y3, void* stream) {
-    YMI_CHECK_ARG(ymi_tensor_ok(y0) && ymi_tensor_ok(y1) && ymi_tensor_ok(y2) && ymi_tensor_ok(y3), "sppf_pool3_fwd: bad tensor");
-    YMI_CHECK_ARG(ymi_same_shape(y0, y1) && ymi_same_shape(y0, y2) && ymi_same_shape(y0, y3), "sppf_pool3_fwd: shapes");
-    YMI_CHECK_ARG(y0->dtype == y1->dtype && y0->dtype == y2->dtype && y0->dtype == y3->dtype, "sppf_pool3_fwd: dtypes");
-    YMI_CHECK_ARG(k >= 1 && (k & 1) && k <= 13, "sppf_pool3_fwd: odd k <= 13");
-    const int cn = y0->dtype == YMI_BF16 ? 8 : 4;
-    const ymi_tensor* ts[4] = {y0, y1, y2, y3};
-    for (auto t : ts)
-        YMI_CHECK_ARG(t->c % cn == 0 && t->ld % cn == 0 && ((uintptr_t)t->data & 15) == 0, "sppf_pool3_fwd: channels/ld/base must be 16-byte aligned");
-    PoolArgs a{};
-    a.y0 = PV{y0->data, y0->ld}; a.y1 = PV{y1->data, y1->ld}; a.y2 = PV{y2->data, y2->ld}; a.y3 = PV{y3->data, y3->ld};
-    a.N = (int)y0->n; a.H = (int)y0->h; a.W = (int)y0->w; a.C = (int)y0->c; a.k = (int)k;
-    size_t lds = 0;
-    YMI_CHECK_ARG(pool_geometry(a.H, a.W, a.k, 0, &a.TH, &a.TW, &lds), "sppf_pool3_fwd: tile does not fit LDS");
-    const int cs = y0->dtype == YMI_BF16 ? 32 : 16;
-    dim3 grid(((a.H + a.TH - 1) / a.TH) * ((a.W + a.TW - 1) / a.TW), (a.C + cs - 1) / cs, a.N);
-    if (y0->dtype == YMI_BF16) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(sppf_pool3_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        hipLaunchKernelGGL(sppf_pool3_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    }
-    YMI_CHECK_LAUNCH("sppf_pool3_fwd");
-    return YMI_OK;
-}
-
 // ---------------------------------------------------------------------------------------- backward
 struct PoolBwdArgs {
-    PV x, gout, gin;
+    PV x, gout, gsrc, gin;  // gin = gsrc + route(gout | x)
     int N, H, W, C;
     int k, TH, TW;
 };
@@ -186,7 +162,7 @@ template <int CN> __device__ __forceinline__ uint64_t load_codes(const unsigned 
     return CN == 8 ? *reinterpret_cast<const uint64_t*>(p) : (uint64_t)*reinterpret_cast<const uint32_t*>(p);
 }
 
-// one stage: gin[s] += sum_{p in window(s)} [argmax(x, window(p)) == s] gout[p]
+// one stage (maps too large for the whole-map kernel below): gin[s] = gsrc[s] + sum_{p in window(s)} [argmax(x, window(p)) == s] gout[p]
 // NCH = 16-byte channel chunks per pixel owned by one workgroup (4: a 64-byte slab, coalesced for large maps;
 // 1: four times as many workgroups, for the small SPPF maps where the launch would not fill the chip otherwise).
 // The arg-max is separable: first the row maximum (and its column code) over the k columns, then the first row
@@ -199,9 +175,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int r = a.k / 2, k = a.k;
     const int tiles_w = (a.W + a.TW - 1) / a.TW;
-    const int th0 = (blockIdx.x / tiles_w) * a.TH, tw0 = (blockIdx.x % tiles_w) * a.TW;
+    // unit order: channel chunk fastest, then tile, then image; consecutive units on one XCD: with one 16-byte chunk per workgroup
+    // eight workgroups share every 128-byte line, and dealt to eight XCDs they fetched it eight times (47 -> see profiles/r03 us)
+    const int unit = xcd_unit(flat_block_id(), gridDim.x * gridDim.y * gridDim.z);
+    const int bslab = unit % gridDim.y, btile = (unit / gridDim.y) % gridDim.x;
+    const int th0 = (btile / tiles_w) * a.TH, tw0 = (btile % tiles_w) * a.TW;
     const int th1 = min(th0 + a.TH, a.H), tw1 = min(tw0 + a.TW, a.W);
-    const int c0 = blockIdx.y * CS, n = blockIdx.z;
+    const int c0 = bslab * CS, n = unit / (gridDim.x * gridDim.y);
     // x on tile + 2r, gout / argmax on tile + r (both clamped to the image)
     const int xh0 = max(th0 - 2 * r, 0), xh1 = min(th1 + 2 * r, a.H), xw0 = max(tw0 - 2 * r, 0), xw1 = min(tw1 + 2 * r, a.W);
     const int gh0 = max(th0 - r, 0), gh1 = min(th1 + r, a.H), gw0 = max(tw0 - r, 0), gw1 = min(tw1 + r, a.W);
@@ -292,7 +272,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(PoolBwdArgs a) {
         if (c0 + ch * CN >= a.C) continue;
         float acc[CN];
         T* dst = gi + (((int64_t)n * a.H + h) * a.W + w) * a.gin.ld + c0 + ch * CN;
-        Chunk<T>::load(dst, acc);
+        Chunk<T>::load(reinterpret_cast<const T*>(a.gsrc.p) + (((int64_t)n * a.H + h) * a.W + w) * a.gsrc.ld + c0 + ch * CN, acc);
         for (int ay = -r; ay <= r; ++ay) {
             const int ph = h + ay;
             if (ph < 0 || ph >= a.H) continue;
@@ -319,9 +299,9 @@ static void launch_pool_bwd_t(const PoolBwdArgs& a, dim3 grid, size_t lds, hipSt
     hipLaunchKernelGGL((maxpool_bwd_kernel<T, NCH>), grid, dim3(256), lds, stream, a);
 }
 
-static int launch_pool_bwd(const ymi_tensor* x, int k, const ymi_tensor* gout, const ymi_tensor* gin, hipStream_t stream) {
+static int launch_pool_bwd(const ymi_tensor* x, int k, PV gout, const ymi_tensor* gsrc, PV gin, hipStream_t stream) {
     PoolBwdArgs a{};
-    a.x = PV{x->data, x->ld}; a.gout = PV{gout->data, gout->ld}; a.gin = PV{gin->data, gin->ld};
+    a.x = PV{x->data, x->ld}; a.gout = gout; a.gsrc = PV{gsrc->data, gsrc->ld}; a.gin = gin;
     a.N = (int)x->n; a.H = (int)x->h; a.W = (int)x->w; a.C = (int)x->c; a.k = k;
     const int r = k / 2;
     const int cn = x->dtype == YMI_BF16 ? 8 : 4;
@@ -355,138 +335,262 @@ static int launch_pool_bwd(const ymi_tensor* x, int k, const ymi_tensor* gout, c
     return YMI_OK;
 }
 
-// ---- the three stages in ONE launch, for maps that fit LDS whole (the SPPF maps of the model: 20x20) ----------------------------
-// A workgroup owns one image and one 16-byte channel chunk: it stages y0, y1, y2 and the running gradient once and runs
-//   g := dy3;  g := dy2 + route(g | y2);  g := dy1 + route(g | y1);  dy0 += route(g | y0)
-// between LDS images, the running gradient kept in f32 (the per-stage kernel rounds it to the tensor dtype between stages).
-// Same arg-max rule and the same separable row / column search as maxpool_bwd_kernel.  Three launches of ~47 us become one.
-struct PoolBwd3Args {
-    PV y[3];    // y0, y1, y2
-    PV dy[4];   // dy0 (in/out), dy1, dy2, dy3 (in)
+// ---- whole-map kernels: a workgroup owns ONE image x ONE 16-byte channel chunk and keeps the whole map in LDS --------------------
+// (the SPPF maps of the model are 20x20 - 40x40 at 1280 input.)  Work units are (chunk fastest, image) through xcd_unit(), so the
+// eight chunks of a 128-byte line run on one XCD.  One chunk per workgroup gives C/8 * N workgroups (1024 for the model) where the
+// tiled kernels' 64-byte slabs gave 256; loops over the K window positions are unrolled (K = 5, 7 compiled; 0: runtime k) with
+// out-of-image positions folded into the compare instead of branched around, so the LDS reads of one item are issued together.
+struct MapArgs {
+    PV y[4];    // forward: y0 (in), y1..y3 (out).  backward: y0, y1, y2 (y[3] unused)
+    PV dy[4];   // backward: dy0..dy3 (in)
+    PV dx;      // backward: out
     int N, H, W, C, k;
 };
 
-template <typename T>
-__global__ __launch_bounds__(256) void sppf_bwd_fused_kernel(PoolBwd3Args a) {
+template <typename T> __device__ __forceinline__ void lds_load_f32(const float* base, int planes_stride, int i, float (&v)[Chunk<T>::N]) {
+    // f32 images are kept as planes of 4 floats per pixel (16-byte LDS accesses at unit stride across lanes: conflict-free)
+#pragma unroll
+    for (int q = 0; q < Chunk<T>::N / 4; ++q) {
+        const float4 t = *reinterpret_cast<const float4*>(base + (size_t)q * planes_stride + (size_t)i * 4);
+        v[q * 4 + 0] = t.x; v[q * 4 + 1] = t.y; v[q * 4 + 2] = t.z; v[q * 4 + 3] = t.w;
+    }
+}
+template <typename T> __device__ __forceinline__ void lds_store_f32(float* base, int planes_stride, int i, const float (&v)[Chunk<T>::N]) {
+#pragma unroll
+    for (int q = 0; q < Chunk<T>::N / 4; ++q)
+        *reinterpret_cast<float4*>(base + (size_t)q * planes_stride + (size_t)i * 4) = make_float4(v[q * 4 + 0], v[q * 4 + 1], v[q * 4 + 2], v[q * 4 + 3]);
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(1024) void sppf_fwd_map_kernel(MapArgs a) {
     constexpr int CN = Chunk<T>::N;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int HW = a.H * a.W, r = a.k / 2, k = a.k;
-    const int c0 = blockIdx.x * CN, n = blockIdx.y;
-    float* G0 = reinterpret_cast<float*>(smem);                       // [HW][CN] running gradient (ping)
-    float* G1 = G0 + (size_t)HW * CN;                                 // (pong)
-    char* X = reinterpret_cast<char*>(G1 + (size_t)HW * CN);          // [HW][16 B] values of the current stage
-    char* RM = X + (size_t)HW * 16;                                   // [HW][16 B] row maxima
-    unsigned char* RC = reinterpret_cast<unsigned char*>(RM + (size_t)HW * 16);  // [HW][CN] column code of the row maximum
-    unsigned char* IDX = RC + (size_t)HW * CN;                        // [HW][CN] arg-max code of the window centred here
+    constexpr int UN = K ? K : 1;  // unroll count of the window loops (runtime k: not unrolled)
+    const int HW = a.H * a.W, k = K ? K : a.k, r = k / 2;
+    const int unit = xcd_unit(flat_block_id(), gridDim.x * gridDim.y);
+    const int c0 = (unit % gridDim.x) * CN, n = unit / gridDim.x;
+    char* X = smem;                       // [HW][16 B] input of the current stage
+    char* RM = smem + (size_t)HW * 16;    // [HW][16 B] row maxima
     const int64_t img = (int64_t)n * HW;
-    // g := dy3
+    {
+        const T* src = reinterpret_cast<const T*>(a.y[0].p);
+        for (int i = threadIdx.x; i < HW; i += blockDim.x)
+            *reinterpret_cast<uint4*>(X + (size_t)i * 16) = *reinterpret_cast<const uint4*>(src + (img + i) * a.y[0].ld + c0);
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int st = 1; st <= 3; ++st) {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const int h = i / a.W, w = i - h * a.W;
+            float m[CN];
+#pragma unroll
+            for (int e = 0; e < CN; ++e) m[e] = NEG_INF;
+#pragma unroll UN
+            for (int d = 0; d < k; ++d) {
+                const int ww = w - r + d;
+                const bool ok = ww >= 0 && ww < a.W;
+                float v[CN];
+                Chunk<T>::load(X + (size_t)(ok ? i - r + d : i) * 16, v);  // (an out-of-image column reads the centre: max unchanged)
+#pragma unroll
+                for (int e = 0; e < CN; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+            Chunk<T>::store(RM + (size_t)i * 16, m);
+        }
+        __syncthreads();
+        T* dst = reinterpret_cast<T*>(a.y[st].p);
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const int h = i / a.W;
+            float m[CN];
+#pragma unroll
+            for (int e = 0; e < CN; ++e) m[e] = NEG_INF;
+#pragma unroll UN
+            for (int d = 0; d < k; ++d) {
+                const int hh = h - r + d;
+                const bool ok = hh >= 0 && hh < a.H;
+                float v[CN];
+                Chunk<T>::load(RM + (size_t)(ok ? i + (d - r) * a.W : i) * 16, v);
+#pragma unroll
+                for (int e = 0; e < CN; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+            Chunk<T>::store(X + (size_t)i * 16, m);  // (X is only read by the row pass: free since the barrier above)
+            Chunk<T>::store(dst + (img + i) * a.y[st].ld + c0, m);
+        }
+        __syncthreads();
+    }
+}
+
+// Backward of the cascade in one launch:  g := dy3;  g := dy2 + route(g | y2);  g := dy1 + route(g | y1);  dx = dy0 + route(g | y0),
+// the running gradient in f32 in LDS.  route() is a deterministic gather with PyTorch's arg-max rule (first maximum in row-major
+// order), and it is SEPARABLE: the arg-max of window p is (first row whose row maximum is the window maximum, that row's first
+// maximal column), so  V[hh][w] = sum_{ph} [rowcode(ph, w) -> hh] g[ph][w]  followed by  out[hh][ww] = sum_{pw} [colcode(hh, pw) -> ww]
+// V[hh][pw]  visits 2k positions per pixel instead of k*k (the sums associate column-first: exact for the dyadic tie fixtures,
+// within f32 rounding of the row-major order otherwise).
+template <typename T, int K>
+__global__ __launch_bounds__(1024) void sppf_bwd_map_kernel(MapArgs a) {
+    constexpr int CN = Chunk<T>::N;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int UN = K ? K : 1;  // unroll count of the window loops (runtime k: not unrolled)
+    const int HW = a.H * a.W, k = K ? K : a.k, r = k / 2;
+    const int unit = xcd_unit(flat_block_id(), gridDim.x * gridDim.y);
+    const int c0 = (unit % gridDim.x) * CN, n = unit / gridDim.x;
+    const int PS = HW * 4;                                            // floats per f32 plane
+    float* G = reinterpret_cast<float*>(smem);                        // [CN/4][HW][4] running gradient
+    char* X = reinterpret_cast<char*>(G + (size_t)HW * CN);           // [HW][16 B] values of the current stage   } later V: [CN/4][HW][4] f32
+    char* RM = X + (size_t)HW * 16;                                   // [HW][16 B] row maxima (f32 tensors: V needs X only) }
+    float* V = reinterpret_cast<float*>(X);
+    unsigned char* RC = reinterpret_cast<unsigned char*>(X + (size_t)HW * 32);  // [HW][CN] column code of the row maximum
+    unsigned char* RR = RC + (size_t)HW * CN;                         // [HW][CN] row code of the window maximum
+    const int64_t img = (int64_t)n * HW;
     {
         const T* gp = reinterpret_cast<const T*>(a.dy[3].p);
-        for (int i = threadIdx.x; i < HW; i += 256) {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             float v[CN];
             Chunk<T>::load(gp + (img + i) * a.dy[3].ld + c0, v);
-#pragma unroll
-            for (int e = 0; e < CN; ++e) G0[(size_t)i * CN + e] = v[e];
+            lds_store_f32<T>(G, PS, i, v);
         }
     }
-    float* gcur = G0;
-    float* gnext = G1;
+#pragma unroll 1
     for (int st = 2; st >= 0; --st) {
         const T* xp = reinterpret_cast<const T*>(a.y[st].p);
-        for (int i = threadIdx.x; i < HW; i += 256) {
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             float v[CN];
             Chunk<T>::load(xp + (img + i) * a.y[st].ld + c0, v);
             Chunk<T>::store(X + (size_t)i * 16, v);
         }
         __syncthreads();
-        // row pass: maximum over the k columns around every position, and its column code
-        for (int i = threadIdx.x; i < HW; i += 256) {
+        // row pass: maximum over the k columns around every position and the code (0..k-1) of its first occurrence
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             const int h = i / a.W, w = i - h * a.W;
             float best[CN];
             int code[CN];
 #pragma unroll
             for (int e = 0; e < CN; ++e) { best[e] = NEG_INF; code[e] = -1; }
-            for (int dx = 0; dx < k; ++dx) {
-                const int ww = w + dx - r;
-                if (ww < 0 || ww >= a.W) continue;
+#pragma unroll UN
+            for (int d = 0; d < k; ++d) {
+                const int ww = w - r + d;
+                const bool ok = ww >= 0 && ww < a.W;
                 float v[CN];
-                Chunk<T>::load(X + (size_t)(h * a.W + ww) * 16, v);
+                Chunk<T>::load(X + (size_t)(ok ? i - r + d : i) * 16, v);
 #pragma unroll
                 for (int e = 0; e < CN; ++e)
-                    if (code[e] < 0 || v[e] > best[e]) {  // first in-image element initialises; then strictly greater wins
+                    if (ok && (code[e] < 0 || v[e] > best[e])) {  // the first in-image element initialises; then strictly greater wins
                         best[e] = v[e];
-                        code[e] = dx;
+                        code[e] = d;
                     }
             }
             Chunk<T>::store(RM + (size_t)i * 16, best);
             store_codes<CN>(RC + (size_t)i * CN, code);
         }
         __syncthreads();
-        // column pass: arg-max code (dy*k + dx) of the window centred at every position
-        for (int i = threadIdx.x; i < HW; i += 256) {
-            const int h = i / a.W, w = i - h * a.W;
+        // column pass: code (0..k-1) of the first row whose row maximum is the maximum of the window centred here
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const int h = i / a.W;
             float best[CN];
             int code[CN];
 #pragma unroll
             for (int e = 0; e < CN; ++e) { best[e] = NEG_INF; code[e] = -1; }
-            for (int dy = 0; dy < k; ++dy) {
-                const int hh = h + dy - r;
-                if (hh < 0 || hh >= a.H) continue;
-                const size_t rp = (size_t)hh * a.W + w;
+#pragma unroll UN
+            for (int d = 0; d < k; ++d) {
+                const int hh = h - r + d;
+                const bool ok = hh >= 0 && hh < a.H;
                 float v[CN];
-                Chunk<T>::load(RM + rp * 16, v);
-                const uint64_t rc = load_codes<CN>(RC + rp * CN);
+                Chunk<T>::load(RM + (size_t)(ok ? i + (d - r) * a.W : i) * 16, v);
 #pragma unroll
                 for (int e = 0; e < CN; ++e)
-                    if (code[e] < 0 || v[e] > best[e]) {
+                    if (ok && (code[e] < 0 || v[e] > best[e])) {
                         best[e] = v[e];
-                        code[e] = dy * k + (int)((rc >> (8 * e)) & 255);
+                        code[e] = d;
                     }
             }
-            store_codes<CN>(IDX + (size_t)i * CN, code);
+            store_codes<CN>(RR + (size_t)i * CN, code);
         }
-        __syncthreads();
-        // gather: gnext[s] = dy_st[s] + sum over windows p containing s whose arg-max is s of gcur[p]
+        __syncthreads();  // X and RM are dead from here: V takes their place
+        // vertical gather: V[hh][w] = sum over window centres (ph, w), ph = hh - r + d, whose maximal row is hh (row code 2r - d)
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
+            const int h = i / a.W;
+            float acc[CN];
+#pragma unroll
+            for (int e = 0; e < CN; ++e) acc[e] = 0.f;
+#pragma unroll UN
+            for (int d = 0; d < k; ++d) {
+                const int ph = h - r + d;
+                const bool ok = ph >= 0 && ph < a.H;
+                const int j = ok ? i + (d - r) * a.W : i;
+                const int want = ok ? 2 * r - d : 255;
+                float g[CN];
+                lds_load_f32<T>(G, PS, j, g);
+                const uint64_t rc = load_codes<CN>(RR + (size_t)j * CN);
+#pragma unroll
+                for (int e = 0; e < CN; ++e)
+                    if ((int)((rc >> (8 * e)) & 255) == want) acc[e] += g[e];
+            }
+            lds_store_f32<T>(V, PS, i, acc);
+        }
+        __syncthreads();  // G is dead from here: the next running gradient is written over it
+        // horizontal gather: out[hh][ww] = dy_st[hh][ww] + sum over pw = ww - r + d with column code 2r - d in row hh of V[hh][pw]
         const T* dp = reinterpret_cast<const T*>(a.dy[st].p);
-        T* op = reinterpret_cast<T*>(a.dy[0].p);
-        for (int i = threadIdx.x; i < HW; i += 256) {
+        T* op = reinterpret_cast<T*>(a.dx.p);
+        for (int i = threadIdx.x; i < HW; i += blockDim.x) {
             const int h = i / a.W, w = i - h * a.W;
             float acc[CN];
             Chunk<T>::load(dp + (img + i) * a.dy[st].ld + c0, acc);
-            for (int ay = -r; ay <= r; ++ay) {
-                const int ph = h + ay;
-                if (ph < 0 || ph >= a.H) continue;
-                for (int ax = -r; ax <= r; ++ax) {
-                    const int pw = w + ax;
-                    if (pw < 0 || pw >= a.W) continue;
-                    const int want = (r - ay) * k + (r - ax);
-                    const size_t gp = (size_t)ph * a.W + pw;
-                    const uint64_t ix = load_codes<CN>(IDX + gp * CN);
+#pragma unroll UN
+            for (int d = 0; d < k; ++d) {
+                const int pw = w - r + d;
+                const bool ok = pw >= 0 && pw < a.W;
+                const int j = ok ? i - r + d : i;
+                const int want = ok ? 2 * r - d : 255;
+                float g[CN];
+                lds_load_f32<T>(V, PS, j, g);
+                const uint64_t rc = load_codes<CN>(RC + (size_t)j * CN);
 #pragma unroll
-                    for (int e = 0; e < CN; ++e)
-                        if ((int)((ix >> (8 * e)) & 255) == want) acc[e] += gcur[gp * CN + e];
-                }
+                for (int e = 0; e < CN; ++e)
+                    if ((int)((rc >> (8 * e)) & 255) == want) acc[e] += g[e];
             }
-            if (st == 0) {
-                Chunk<T>::store(op + (img + i) * a.dy[0].ld + c0, acc);
-            } else {
-#pragma unroll
-                for (int e = 0; e < CN; ++e) gnext[(size_t)i * CN + e] = acc[e];
-            }
+            if (st == 0) Chunk<T>::store(op + (img + i) * a.dx.ld + c0, acc);
+            else lds_store_f32<T>(G, PS, i, acc);
         }
-        __syncthreads();  // gnext complete; X / RM / RC / IDX free for the next stage
-        float* t = gcur;
-        gcur = gnext;
-        gnext = t;
+        __syncthreads();  // V (= X, RM), RC, RR free for the next stage; G complete
     }
 }
 
-static size_t sppf_bwd_fused_lds(int hw, int cn) { return (size_t)hw * (2 * cn * sizeof(float) + 16 + 16 + 2 * cn); }
+// LDS of the whole-map kernels per pixel: forward 2 x 16 B; backward G (4 CN) + X|RM / V (32 B >= 4 CN) + RC + RR (2 CN)
+static size_t sppf_map_lds(int hw, int cn, bool bwd) { return (size_t)hw * (bwd ? 4 * cn + 32 + 2 * cn : 32); }
+static const size_t SPPF_MAP_LDS_MAX = 150 * 1024;
+static int sppf_map_threads(int hw) { const int t = (hw + 63) / 64 * 64; return t < 64 ? 64 : (t > 1024 ? 1024 : t); }
 
-// dy2 += route(dy3 | y2); dy1 += route(dy2 | y1); dy0 += route(dy1 | y0).  dy1 and dy2 are modified in place.
-extern "C" int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, const ymi_tensor* y2, int64_t k, const ymi_tensor* dy1,
-                                  const ymi_tensor* dy2, const ymi_tensor* dy3, const ymi_tensor* dy0_accum, void* stream) {
-    const ymi_tensor* ts[7] = {y0, y1, y2, dy1, dy2, dy3, dy0_accum};
+template <typename T>
+static void launch_sppf_map(bool bwd, const MapArgs& a, size_t lds, hipStream_t s) {
+    constexpr int CN = Chunk<T>::N;
+    const dim3 grid((unsigned)(a.C / CN), (unsigned)a.N), block((unsigned)sppf_map_threads(a.H * a.W));
+#define YMI_SPPF_MAP(KERN, KK)                                                                                                    \
+    do {                                                                                                                          \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(KERN<T, KK>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+        hipLaunchKernelGGL((KERN<T, KK>), grid, block, lds, s, a);                                                                \
+    } while (0)
+    if (bwd) {
+        if (a.k == 5) YMI_SPPF_MAP(sppf_bwd_map_kernel, 5);
+        else if (a.k == 7) YMI_SPPF_MAP(sppf_bwd_map_kernel, 7);
+        else YMI_SPPF_MAP(sppf_bwd_map_kernel, 0);
+    } else {
+        if (a.k == 5) YMI_SPPF_MAP(sppf_fwd_map_kernel, 5);
+        else if (a.k == 7) YMI_SPPF_MAP(sppf_fwd_map_kernel, 7);
+        else YMI_SPPF_MAP(sppf_fwd_map_kernel, 0);
+    }
+#undef YMI_SPPF_MAP
+}
+
+extern "C" int64_t ymi_sppf_pool3_bwd_workspace(int64_t n, int64_t h, int64_t w, int64_t c, int dtype) {
+    const int cn = dtype == YMI_BF16 ? 8 : 4;
+    if (sppf_map_lds((int)(h * w), cn, true) <= SPPF_MAP_LDS_MAX) return 0;
+    return 2 * n * h * w * c * (int64_t)ymi_esize(dtype);  // the two intermediate gradients of the per-stage path
+}
+
+// dx = dy0 + route(dy1 + route(dy2 + route(dy3 | y2) | y1) | y0); no input is modified.
+extern "C" int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, const ymi_tensor* y2, int64_t k, const ymi_tensor* dy0,
+                                  const ymi_tensor* dy1, const ymi_tensor* dy2, const ymi_tensor* dy3, const ymi_tensor* dx, void* workspace,
+                                  int64_t workspace_bytes, void* stream) {
+    const ymi_tensor* ts[8] = {y0, y1, y2, dy0, dy1, dy2, dy3, dx};
     const int cn = (y0 && y0->dtype == YMI_BF16) ? 8 : 4;
     for (auto t : ts) {
         YMI_CHECK_ARG(ymi_tensor_ok(t) && ymi_same_shape(t, y0) && t->dtype == y0->dtype, "sppf_pool3_bwd: tensors must share shape and dtype");
@@ -494,23 +598,63 @@ extern "C" int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, co
     }
     YMI_CHECK_ARG(k >= 1 && (k & 1) && k <= 13, "sppf_pool3_bwd: odd k <= 13");
     hipStream_t s = (hipStream_t)stream;
-    static const int fused_env = getenv("YMI_SPPF_BWD_FUSED") ? atoi(getenv("YMI_SPPF_BWD_FUSED")) : 0;  // 1: all three stages in one launch - measured SLOWER (14.88 vs 14.76 ms/step on the same box: the gather is VALU/LDS-bound, not launch-bound, and the f32 running gradient halves the resident workgroups)
     const int hw = (int)(y0->h * y0->w);
-    if (fused_env && y0->c % cn == 0 && sppf_bwd_fused_lds(hw, cn) <= 64 * 1024) {  // whole map in LDS (dy1 / dy2 are left untouched)
-        PoolBwd3Args a{};
+    const size_t lds = sppf_map_lds(hw, cn, true);
+    if (lds <= SPPF_MAP_LDS_MAX) {
+        MapArgs a{};
         a.y[0] = PV{y0->data, y0->ld}; a.y[1] = PV{y1->data, y1->ld}; a.y[2] = PV{y2->data, y2->ld};
-        a.dy[0] = PV{dy0_accum->data, dy0_accum->ld}; a.dy[1] = PV{dy1->data, dy1->ld}; a.dy[2] = PV{dy2->data, dy2->ld}; a.dy[3] = PV{dy3->data, dy3->ld};
+        a.dy[0] = PV{dy0->data, dy0->ld}; a.dy[1] = PV{dy1->data, dy1->ld}; a.dy[2] = PV{dy2->data, dy2->ld}; a.dy[3] = PV{dy3->data, dy3->ld};
+        a.dx = PV{dx->data, dx->ld};
         a.N = (int)y0->n; a.H = (int)y0->h; a.W = (int)y0->w; a.C = (int)y0->c; a.k = (int)k;
-        const size_t lds = sppf_bwd_fused_lds(hw, cn);
-        dim3 grid((unsigned)(y0->c / cn), (unsigned)y0->n);
-        if (y0->dtype == YMI_BF16) hipLaunchKernelGGL((sppf_bwd_fused_kernel<bf16_t>), grid, dim3(256), lds, s, a);
-        else hipLaunchKernelGGL((sppf_bwd_fused_kernel<float>), grid, dim3(256), lds, s, a);
-        YMI_CHECK_LAUNCH("sppf_pool3_bwd(fused)");
+        if (y0->dtype == YMI_BF16) launch_sppf_map<bf16_t>(true, a, lds, s);
+        else launch_sppf_map<float>(true, a, lds, s);
+        YMI_CHECK_LAUNCH("sppf_pool3_bwd(map)");
         return YMI_OK;
     }
-    int rc = launch_pool_bwd(y2, (int)k, dy3, dy2, s);
+    const int64_t one = y0->n * y0->h * y0->w * y0->c * (int64_t)ymi_esize(y0->dtype);
+    YMI_CHECK_ARG(workspace && workspace_bytes >= 2 * one && ((uintptr_t)workspace & 15) == 0, "sppf_pool3_bwd: workspace (see ymi_sppf_pool3_bwd_workspace)");
+    const PV g2{workspace, y0->c}, g1{(char*)workspace + one, y0->c};
+    int rc = launch_pool_bwd(y2, (int)k, PV{dy3->data, dy3->ld}, dy2, g2, s);
     if (rc) return rc;
-    rc = launch_pool_bwd(y1, (int)k, dy2, dy1, s);
+    rc = launch_pool_bwd(y1, (int)k, g2, dy1, g1, s);
     if (rc) return rc;
-    return launch_pool_bwd(y0, (int)k, dy1, dy0_accum, s);
+    return launch_pool_bwd(y0, (int)k, g1, dy0, PV{dx->data, dx->ld}, s);
 }
+
+extern "C" int ymi_sppf_pool3_fwd(const ymi_tensor* y0, int64_t k, const ymi_tensor* y1, const ymi_tensor* y2, const ymi_tensor* y3, void* stream) {
+    YMI_CHECK_ARG(ymi_tensor_ok(y0) && ymi_tensor_ok(y1) && ymi_tensor_ok(y2) && ymi_tensor_ok(y3), "sppf_pool3_fwd: bad tensor");
+    YMI_CHECK_ARG(ymi_same_shape(y0, y1) && ymi_same_shape(y0, y2) && ymi_same_shape(y0, y3), "sppf_pool3_fwd: shapes");
+    YMI_CHECK_ARG(y0->dtype == y1->dtype && y0->dtype == y2->dtype && y0->dtype == y3->dtype, "sppf_pool3_fwd: dtypes");
+    YMI_CHECK_ARG(k >= 1 && (k & 1) && k <= 13, "sppf_pool3_fwd: odd k <= 13");
+    const int cn = y0->dtype == YMI_BF16 ? 8 : 4;
+    const ymi_tensor* ts[4] = {y0, y1, y2, y3};
+    for (auto t : ts)
+        YMI_CHECK_ARG(t->c % cn == 0 && t->ld % cn == 0 && ((uintptr_t)t->data & 15) == 0, "sppf_pool3_fwd: channels/ld/base must be 16-byte aligned");
+    if (sppf_map_lds((int)(y0->h * y0->w), cn, false) <= SPPF_MAP_LDS_MAX) {  // whole map per (image, 16-byte chunk) workgroup
+        MapArgs m{};
+        m.y[0] = PV{y0->data, y0->ld}; m.y[1] = PV{y1->data, y1->ld}; m.y[2] = PV{y2->data, y2->ld}; m.y[3] = PV{y3->data, y3->ld};
+        m.N = (int)y0->n; m.H = (int)y0->h; m.W = (int)y0->w; m.C = (int)y0->c; m.k = (int)k;
+        const size_t mlds = sppf_map_lds((int)(y0->h * y0->w), cn, false);
+        if (y0->dtype == YMI_BF16) launch_sppf_map<bf16_t>(false, m, mlds, (hipStream_t)stream);
+        else launch_sppf_map<float>(false, m, mlds, (hipStream_t)stream);
+        YMI_CHECK_LAUNCH("sppf_pool3_fwd(map)");
+        return YMI_OK;
+    }
+    PoolArgs a{};
+    a.y0 = PV{y0->data, y0->ld}; a.y1 = PV{y1->data, y1->ld}; a.y2 = PV{y2->data, y2->ld}; a.y3 = PV{y3->data, y3->ld};
+    a.N = (int)y0->n; a.H = (int)y0->h; a.W = (int)y0->w; a.C = (int)y0->c; a.k = (int)k;
+    size_t lds = 0;
+    YMI_CHECK_ARG(pool_geometry(a.H, a.W, a.k, 0, &a.TH, &a.TW, &lds), "sppf_pool3_fwd: tile does not fit LDS");
+    const int cs = y0->dtype == YMI_BF16 ? 32 : 16;
+    dim3 grid(((a.H + a.TH - 1) / a.TH) * ((a.W + a.TW - 1) / a.TW), (a.C + cs - 1) / cs, a.N);
+    if (y0->dtype == YMI_BF16) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(sppf_pool3_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sppf_pool3_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipLaunchKernelGGL(sppf_pool3_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, a);
+    }
+    YMI_CHECK_LAUNCH("sppf_pool3_fwd");
+    return YMI_OK;
+}
+

@@ -1051,16 +1051,18 @@ class _SppfPool(torch.autograd.Function):
         (cat,) = ctx.saved_tensors
         c, k = ctx.c, ctx.k
         n, _, h, w = cat.shape
-        work = empty_nhwc(n, 4 * c, h, w, cat.dtype, cat.device)
-        work.copy_(g)  # private copy: the routing below accumulates in place
+        g = grad_nhwc(g, cat.dtype)
         y = [cat[:, i * c : (i + 1) * c] for i in range(3)]
-        d = [work[:, i * c : (i + 1) * c] for i in range(4)]
+        d = [g[:, i * c : (i + 1) * c] for i in range(4)]
+        dx = empty_nhwc(n, c, h, w, cat.dtype, cat.device)
+        nws = int(L().ymi_sppf_pool3_bwd_workspace(n, h, w, c, ymi_dtype(cat.dtype)))
+        ws = torch.empty(nws, dtype=torch.uint8, device=cat.device) if nws else None
         check(
-            L().ymi_sppf_pool3_bwd(_byref(as_ymi(y[0])), _byref(as_ymi(y[1])), _byref(as_ymi(y[2])), k, _byref(as_ymi(d[1])),
-                                   _byref(as_ymi(d[2])), _byref(as_ymi(d[3])), _byref(as_ymi(d[0])), stream_ptr()),
+            L().ymi_sppf_pool3_bwd(_byref(as_ymi(y[0])), _byref(as_ymi(y[1])), _byref(as_ymi(y[2])), k, _byref(as_ymi(d[0])), _byref(as_ymi(d[1])),
+                                   _byref(as_ymi(d[2])), _byref(as_ymi(d[3])), _byref(as_ymi(dx)), ptr(ws) if ws is not None else None, nws, stream_ptr()),
             "sppf_pool3_bwd",
         )
-        return d[0], None, None
+        return dx, None, None
 
 
 def sppf_pool_cat(y0, k, cat=None):

@@ -187,12 +187,15 @@ int ymi_wgrad_reduce_batch(const ymi_wgrad_pending* host_records, int32_t n, ymi
  * nn/modules/block.py:220,225.  One LDS-staged kernel; y1..y3 are usually channel slices of the
  * concat buffer that SPPF.cv2 reads. */
 int ymi_sppf_pool3_fwd(const ymi_tensor* y0, int64_t k, const ymi_tensor* y1, const ymi_tensor* y2, const ymi_tensor* y3, void* stream);
-/* Adjoint of the cascade, stage by stage as a deterministic gather: dy2 += route(dy3|y2);
- * dy1 += route(dy2|y1); dy0 += route(dy1|y0), each window's gradient going to its first arg-max in
- * row-major order (PyTorch's max_pool2d tie rule).  dy1, dy2 may be modified in place (scratch); dy0 must
- * already hold the direct gradient of y0.  Maps that fit LDS whole run all three stages in one launch. */
-int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, const ymi_tensor* y2, int64_t k, const ymi_tensor* dy1,
-                       const ymi_tensor* dy2, const ymi_tensor* dy3, const ymi_tensor* dy0_accum, void* stream);
+/* Adjoint of the cascade: dx = dy0 + route(dy1 + route(dy2 + route(dy3 | y2) | y1) | y0), a deterministic gather in which every
+ * window's gradient goes to its first arg-max in row-major order (PyTorch's max_pool2d tie rule).  No input is modified; dx may
+ * not alias them.  Maps that fit LDS whole (<= ~2100 pixels in bf16) run in one launch with the running gradient in f32 and need
+ * no workspace; larger maps run stage by stage through `workspace` (ymi_sppf_pool3_bwd_workspace bytes, 16-byte aligned), the
+ * intermediate gradients rounded to the tensor dtype like the reference's. */
+int64_t ymi_sppf_pool3_bwd_workspace(int64_t n, int64_t h, int64_t w, int64_t c, int dtype);
+int ymi_sppf_pool3_bwd(const ymi_tensor* y0, const ymi_tensor* y1, const ymi_tensor* y2, int64_t k, const ymi_tensor* dy0,
+                       const ymi_tensor* dy1, const ymi_tensor* dy2, const ymi_tensor* dy3, const ymi_tensor* dx, void* workspace,
+                       int64_t workspace_bytes, void* stream);
 
 /* -------------------------------------------------------------------------------- CBAM ---- */
 

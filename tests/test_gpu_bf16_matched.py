@@ -209,9 +209,16 @@ def test_maxpool_cascade_routes_ties_like_the_reference(k):
     assert torch.equal(gx.float().cpu(), t(d["g.x"]))
 
 
-@pytest.mark.parametrize("k,shape", [(5, (8, 256, 20, 20)), (7, (8, 256, 20, 20)), (5, (2, 64, 40, 40))])
-def test_maxpool_cascade_ties_at_model_shapes(k, shape):
-    """the same at the model's SPPF shapes against the oracle (whose tie rule the fixtures above pin to the reference)."""
+@pytest.mark.parametrize("k,shape,dtype", [
+    (5, (8, 256, 20, 20), torch.float32), (7, (8, 256, 20, 20), torch.float32), (5, (2, 64, 40, 40), torch.float32),
+    (5, (8, 256, 20, 20), torch.bfloat16), (7, (4, 64, 20, 20), torch.bfloat16), (5, (2, 64, 40, 40), torch.bfloat16),
+    (9, (2, 8, 13, 17), torch.float32),    # odd map, a window size without a compiled specialisation
+    (3, (1, 16, 64, 64), torch.float32),   # backward too large for the whole-map kernel: stage by stage through the workspace
+    (3, (1, 16, 96, 96), torch.float32),   # forward too: the tiled kernel
+])
+def test_maxpool_cascade_ties_at_model_shapes(k, shape, dtype):
+    """the same at the model's SPPF shapes against the oracle (whose tie rule the fixtures above pin to the reference); bf16: the
+    values are exact and the gradient, summed exactly in f32, is rounded once (whole-map kernel: the running gradient stays f32)."""
     import oracle.modules as OM
     from improving_yolov8_cbam_swinblock_amd import ops
 
@@ -225,10 +232,10 @@ def test_maxpool_cascade_ties_at_model_shapes(k, shape):
     co = torch.cat(ys, 1)
     (go,) = torch.autograd.grad(co, xo, gy)
     xg = x.to(dev()).requires_grad_(True)
-    cg = ops.sppf_pool_cat(ops.to_internal(xg, torch.float32), k)
+    cg = ops.sppf_pool_cat(ops.to_internal(xg, dtype), k)
     (gg,) = torch.autograd.grad(cg, xg, gy.to(dev()))
     assert torch.equal(cg.float().cpu(), co.detach())
-    assert torch.equal(gg.float().cpu(), go)
+    assert torch.equal(gg.float().cpu(), go.to(dtype).float())
 
 
 @pytest.mark.parametrize("name", ["cbam_ties_c32", "cbam_ties_flatca_c32"])

@@ -10,7 +10,7 @@ CATS = [
     ("wgrad_reduce", ("wgrad_reduce", "wgrad_stage")),
     ("bn_fwd", ("scale_shift_act", "bn_finalize", "stat_rows")),
     ("bn_bwd", ("bn_act_bwd", "chan_reduce")),
-    ("pool", ("pool",)),
+    ("pool", ("pool", "sppf_")),
     ("cbam", ("cbam",)),
     ("swin", ("window", "layernorm", "attn", "gelu", "token")),
     ("loss", ("decode_kernel", "metric_kernel", "topk_kernel", "assign_kernel", "posmax", "finalize_kernel", "loss_kernel", "loss_final", "targets_kernel")),
