@@ -36,13 +36,26 @@ __global__ __launch_bounds__(256) void cbam_pool_kernel(CV x, int HW, int C, flo
 #pragma unroll
     for (int r = 0; r < 4; ++r) mx[r] = -__builtin_inff();
     if (c < C) {
-        for (int p = py; p < HW; p += PY) {
+        int p = py;
+        for (; p + 3 * PY < HW; p += 4 * PY) {  // four pixels in flight per lane (the loop is a chain of load latencies otherwise)
+            float v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) Pack<T, 4>::load(xp + (int64_t)(p + u * PY) * x.ld + c, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    sum[r] += v[u][r];
+                    if (v[u][r] > mx[r]) { mx[r] = v[u][r]; ix[r] = p + u * PY; }  // strictly greater: first maximum in scan order
+                }
+        }
+        for (; p < HW; p += PY) {
             float v[4];
             Pack<T, 4>::load(xp + (int64_t)p * x.ld + c, v);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sum[r] += v[r];
-                if (v[r] > mx[r]) { mx[r] = v[r]; ix[r] = p; }  // strictly greater: first maximum in scan order
+                if (v[r] > mx[r]) { mx[r] = v[r]; ix[r] = p; }
             }
         }
     }
@@ -71,20 +84,23 @@ __global__ __launch_bounds__(256) void cbam_pool_kernel(CV x, int HW, int C, flo
     }
 }
 
-// one block per image: hidden = relu(W1 avg) + relu(W1 max); ca = sigmoid(W2 hidden)
-__global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ w2,
-                                                       int C, int Hd, float* __restrict__ ca) {
+// one block (any multiple of 64 threads; launched with 1024) per image: hidden = relu(W1 avg) + relu(W1 max); ca = sigmoid(W2 hidden).
+// Pure latency: three dependent rounds of loads; every round's loads are issued together (unrolled), one hidden unit or two per wave.
+__global__ __launch_bounds__(1024) void cbam_mlp_kernel(const float* __restrict__ pooled, const float* __restrict__ w1, const float* __restrict__ w2,
+                                                        int C, int Hd, float* __restrict__ ca) {
     extern __shared__ float sh[];  // [2][C] pooled, [Hd] hidden sum
     float* sp = sh;
     float* hs = sh + 2 * C;
-    const int n = blockIdx.x;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sp[i] = pooled[(int64_t)n * 2 * C + i];
+    const int n = blockIdx.x, nt = blockDim.x, nw = nt >> 6;
+    for (int i = threadIdx.x; i < 2 * C; i += nt) sp[i] = pooled[(int64_t)n * 2 * C + i];
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int h = wave; h < Hd; h += 4) {
+    for (int h = wave; h < Hd; h += nw) {
         float a = 0.f, m = 0.f;
+        const float* wr = w1 + (int64_t)h * C;
+#pragma unroll 8
         for (int c = lane; c < C; c += 64) {
-            const float w = w1[(int64_t)h * C + c];
+            const float w = wr[c];
             a += w * sp[c];
             m += w * sp[C + c];
         }
@@ -93,9 +109,11 @@ __global__ __launch_bounds__(256) void cbam_mlp_kernel(const float* __restrict__
         if (lane == 0) hs[h] = fmaxf(a, 0.f) + fmaxf(m, 0.f);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += nt) {
         float z = 0.f;
-        for (int h = 0; h < Hd; ++h) z += w2[(int64_t)c * Hd + h] * hs[h];
+        const float* wr = w2 + (int64_t)c * Hd;
+#pragma unroll 8
+        for (int h = 0; h < Hd; ++h) z += wr[h] * hs[h];
         ca[(int64_t)n * C + c] = sigmoidf_(z);
     }
 }
@@ -185,12 +203,12 @@ extern "C" int ymi_cbam_fwd(const ymi_tensor* x, const float* w1, const float* w
     const size_t mlp_lds = (size_t)(2 * C + hidden) * sizeof(float);
     if (x->dtype == YMI_BF16) {
         hipLaunchKernelGGL(cbam_pool_kernel<bf16_t>, gp, dim3(256), 0, s, xv, HW, C, pooled, pool_argmax);
-        hipLaunchKernelGGL(cbam_mlp_kernel, dim3(N), dim3(256), mlp_lds, s, pooled, w1, w2, C, (int)hidden, ca);
+        hipLaunchKernelGGL(cbam_mlp_kernel, dim3(N), dim3(1024), mlp_lds, s, pooled, w1, w2, C, (int)hidden, ca);
         hipLaunchKernelGGL(cbam_stats_kernel<bf16_t>, gw, dim3(256), 0, s, xv, NP, HW, C, ca, smap, smap_argmax);
         hipLaunchKernelGGL(cbam_apply_kernel<bf16_t>, gw, dim3(256), 0, s, xv, ov, N, H, W, C, ca, smap, wsa, (int)ksa, sa);
     } else {
         hipLaunchKernelGGL(cbam_pool_kernel<float>, gp, dim3(256), 0, s, xv, HW, C, pooled, pool_argmax);
-        hipLaunchKernelGGL(cbam_mlp_kernel, dim3(N), dim3(256), mlp_lds, s, pooled, w1, w2, C, (int)hidden, ca);
+        hipLaunchKernelGGL(cbam_mlp_kernel, dim3(N), dim3(1024), mlp_lds, s, pooled, w1, w2, C, (int)hidden, ca);
         hipLaunchKernelGGL(cbam_stats_kernel<float>, gw, dim3(256), 0, s, xv, NP, HW, C, ca, smap, smap_argmax);
         hipLaunchKernelGGL(cbam_apply_kernel<float>, gw, dim3(256), 0, s, xv, ov, N, H, W, C, ca, smap, wsa, (int)ksa, sa);
     }
@@ -298,20 +316,21 @@ __global__ __launch_bounds__(256) void cbam_bwd_dx_kernel(CV x, CV dout, CV dx, 
 }
 
 // B3: per image: dca -> dz -> hidden grads -> d_avg, d_max ; stores dz[N][C], hsum[N][Hd], dpre[N][2][Hd]
-__global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restrict__ dcap, int PB, const float* __restrict__ pooled,
-                                                           const float* __restrict__ ca, const float* __restrict__ w1,
-                                                           const float* __restrict__ w2, int C, int Hd, float* __restrict__ dz,
-                                                           float* __restrict__ hsum, float* __restrict__ dpre, float* __restrict__ dpool) {
+__global__ __launch_bounds__(1024) void cbam_bwd_mlp_kernel(const float* __restrict__ dcap, int PB, const float* __restrict__ pooled,
+                                                            const float* __restrict__ ca, const float* __restrict__ w1,
+                                                            const float* __restrict__ w2, int C, int Hd, float* __restrict__ dz,
+                                                            float* __restrict__ hsum, float* __restrict__ dpre, float* __restrict__ dpool) {
     extern __shared__ float sh[];  // [2C] pooled | [C] dz | [2Hd] pre (avg,max) | [Hd] dh
     float* sp = sh;
     float* sdz = sh + 2 * C;
     float* pre = sdz + C;
     float* dh = pre + 2 * Hd;
-    const int n = blockIdx.x;
+    const int n = blockIdx.x, nt = blockDim.x, nw = nt >> 6;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int i = threadIdx.x; i < 2 * C; i += 256) sp[i] = pooled[(int64_t)n * 2 * C + i];
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int i = threadIdx.x; i < 2 * C; i += nt) sp[i] = pooled[(int64_t)n * 2 * C + i];
+    for (int c = threadIdx.x; c < C; c += nt) {
         float s = 0.f;
+#pragma unroll 8
         for (int b = 0; b < PB; ++b) s += dcap[((int64_t)n * PB + b) * C + c];
         const float a = ca[(int64_t)n * C + c];
         const float g = s * a * (1.f - a);
@@ -319,8 +338,9 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restri
         dz[(int64_t)n * C + c] = g;
     }
     __syncthreads();
-    for (int h = wave; h < Hd; h += 4) {
+    for (int h = wave; h < Hd; h += nw) {
         float a = 0.f, m = 0.f, g = 0.f;
+#pragma unroll 8
         for (int c = lane; c < C; c += 64) {
             const float w = w1[(int64_t)h * C + c];
             a += w * sp[c];
@@ -336,8 +356,9 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restri
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += nt) {
         float da = 0.f, dm = 0.f;
+#pragma unroll 8
         for (int h = 0; h < Hd; ++h) {
             const float w = w1[(int64_t)h * C + c];
             da += (pre[h] > 0.f ? dh[h] : 0.f) * w;
@@ -353,16 +374,18 @@ __global__ __launch_bounds__(256) void cbam_bwd_mlp_kernel(const float* __restri
 __global__ void cbam_bwd_w_kernel(const float* __restrict__ dz, const float* __restrict__ hsum, const float* __restrict__ dpre,
                                   const float* __restrict__ pooled, int N, int C, int Hd, float* __restrict__ dw1, float* __restrict__ dw2) {
     const int total = C * Hd;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        {
+    for (int i2 = blockIdx.x * blockDim.x + threadIdx.x; i2 < 2 * total; i2 += gridDim.x * blockDim.x) {
+        const int i = i2 < total ? i2 : i2 - total;
+        if (i2 < total) {
             const int c = i / Hd, h = i % Hd;  // dw2 [C][Hd]
             float s = 0.f;
+#pragma unroll 8
             for (int n = 0; n < N; ++n) s += dz[(int64_t)n * C + c] * hsum[(int64_t)n * Hd + h];
             dw2[i] = s;
-        }
-        {
+        } else {
             const int h = i / C, c = i % C;  // dw1 [Hd][C]
             float s = 0.f;
+#pragma unroll 8
             for (int n = 0; n < N; ++n)
                 s += dpre[((int64_t)n * 2 + 0) * Hd + h] * pooled[((int64_t)n * 2 + 0) * C + c] +
                      dpre[((int64_t)n * 2 + 1) * Hd + h] * pooled[((int64_t)n * 2 + 1) * C + c];
@@ -372,43 +395,60 @@ __global__ void cbam_bwd_w_kernel(const float* __restrict__ dz, const float* __r
 }
 
 // B5: dwsa[j][t] = sum_{n,p} du[p] * sm[p + off_t][j]   (one block per (j,t))
-__global__ __launch_bounds__(256) void cbam_bwd_wsa_kernel(const float* __restrict__ du, const float* __restrict__ smap, int N, int H, int W, int K,
-                                                           float* __restrict__ dwsa) {
-    __shared__ float red[4];
+__global__ __launch_bounds__(1024) void cbam_bwd_wsa_kernel(const float* __restrict__ du, const float* __restrict__ smap, int N, int H, int W, int K,
+                                                            float* __restrict__ dwsa) {
+    __shared__ float red[16];
     const int t = blockIdx.x % (K * K), j = blockIdx.x / (K * K);
     const int R = K / 2, dy = t / K - R, dx = t % K - R;
-    const int64_t NP = (int64_t)N * H * W;
-    float s = 0.f;
-    for (int64_t p = threadIdx.x; p < NP; p += 256) {
-        const int w = (int)(p % W), h = (int)((p / W) % H);
-        const int hh = h + dy, ww = w + dx;
-        if (hh >= 0 && hh < H && ww >= 0 && ww < W) s += du[p] * smap[(p + (int64_t)dy * W + dx) * 2 + j];
+    const uint32_t NP = (uint32_t)N * H * W, uw = (uint32_t)W, uh = (uint32_t)H;  // host: N*H*W < 2^31
+    const int shift = dy * W + dx;
+    float s0 = 0.f, s1 = 0.f;  // two chains: even / odd trips (fixed order: deterministic)
+    uint32_t p = threadIdx.x;
+    for (; p + blockDim.x < NP; p += 2 * blockDim.x) {
+        const uint32_t q = p + blockDim.x;
+        const uint32_t r0 = p / uw, r1 = q / uw;
+        const int w0 = (int)(p - r0 * uw), h0 = (int)(r0 % uh), w1 = (int)(q - r1 * uw), h1 = (int)(r1 % uh);
+        const bool ok0 = h0 + dy >= 0 && h0 + dy < H && w0 + dx >= 0 && w0 + dx < W;
+        const bool ok1 = h1 + dy >= 0 && h1 + dy < H && w1 + dx >= 0 && w1 + dx < W;
+        const float a0 = ok0 ? du[p] * smap[((int64_t)p + shift) * 2 + j] : 0.f;
+        const float a1 = ok1 ? du[q] * smap[((int64_t)q + shift) * 2 + j] : 0.f;
+        s0 += a0;
+        s1 += a1;
     }
-    s = wave_sum(s);
+    if (p < NP) {
+        const uint32_t r0 = p / uw;
+        const int w0 = (int)(p - r0 * uw), h0 = (int)(r0 % uh);
+        if (h0 + dy >= 0 && h0 + dy < H && w0 + dx >= 0 && w0 + dx < W) s0 += du[p] * smap[((int64_t)p + shift) * 2 + j];
+    }
+    float s = wave_sum(s0 + s1);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) dwsa[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        float tot = 0.f;
+        for (int q = 0; q < (int)(blockDim.x >> 6); ++q) tot += red[q];
+        dwsa[blockIdx.x] = tot;
+    }
 }
 
 // B6: dx[p,c] += d_avg[c]/HW + [p == argmax_p(c)] * d_max[c]
 template <typename T>
 __global__ void cbam_bwd_pool_kernel(CV dx, int64_t NP, int HW, int C, const float* __restrict__ dpool, const int* __restrict__ amax) {
-    const int groups = C / 4;
-    const int64_t total = NP * groups;
+    const uint32_t groups = (uint32_t)(C / 4), total = (uint32_t)NP * groups, uhw = (uint32_t)HW;  // host: NP * C / 4 < 2^31
     T* dp = reinterpret_cast<T*>(const_cast<void*>(dx.p));
     const float inv = 1.f / (float)HW;
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int g = (int)(i % groups);
-        const int64_t p = i / groups;
-        const int n = (int)(p / HW), q = (int)(p % HW);
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t p = i / groups, g = i - p * groups;
+        const uint32_t n = p / uhw, q = p - n * uhw;
         float v[4];
-        Pack<T, 4>::load(dp + p * dx.ld + g * 4, v);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = g * 4 + r;
-            v[r] += dpool[((int64_t)n * 2 + 0) * C + c] * inv + (amax[(int64_t)n * C + c] == q ? dpool[((int64_t)n * 2 + 1) * C + c] : 0.f);
-        }
-        Pack<T, 4>::store(dp + p * dx.ld + g * 4, v);
+        Pack<T, 4>::load(dp + (int64_t)p * dx.ld + g * 4, v);
+        const float4 da = *reinterpret_cast<const float4*>(dpool + ((int64_t)n * 2 + 0) * C + g * 4);
+        const float4 dm = *reinterpret_cast<const float4*>(dpool + ((int64_t)n * 2 + 1) * C + g * 4);
+        const int4 am = *reinterpret_cast<const int4*>(amax + (int64_t)n * C + g * 4);
+        v[0] += da.x * inv + (am.x == (int)q ? dm.x : 0.f);
+        v[1] += da.y * inv + (am.y == (int)q ? dm.y : 0.f);
+        v[2] += da.z * inv + (am.z == (int)q ? dm.z : 0.f);
+        v[3] += da.w * inv + (am.w == (int)q ? dm.w : 0.f);
+        Pack<T, 4>::store(dp + (int64_t)p * dx.ld + g * 4, v);
     }
 }
 
@@ -422,7 +462,7 @@ static int cbam_pb(int HW) {
 extern "C" size_t ymi_cbam_bwd_workspace(int64_t n, int64_t h, int64_t w, int64_t c, int64_t hidden) {
     const int pb = cbam_pb((int)(h * w));
     // du [N*H*W] | dcap [N][PB][C] | dz [N][C] | hsum [N][Hd] | dpre [N][2][Hd] | dpool [N][2][C]
-    return (size_t)(n * h * w + n * pb * c + n * c + n * hidden + 2 * n * hidden + 2 * n * c) * sizeof(float) + 256;
+    return (size_t)(n * h * w + n * pb * c + n * c + n * hidden + 2 * n * hidden + 2 * n * c + 6 * 4) * sizeof(float) + 256;
 }
 
 extern "C" int ymi_cbam_bwd(const ymi_tensor* x, const ymi_tensor* dout, const float* w1, const float* w2, int64_t hidden, const float* wsa,
@@ -441,12 +481,15 @@ extern "C" int ymi_cbam_bwd(const ymi_tensor* x, const ymi_tensor* dout, const f
     }
     const int PB = cbam_pb(HW);
     const int64_t NP = (int64_t)N * HW;
+    YMI_CHECK_ARG(NP * (C / 4) < ((int64_t)1 << 31), "cbam_bwd: N*H*W*C/4 must stay below 2^31");
+    auto up4 = [](int64_t v) { return (v + 3) / 4 * 4; };  // sub-buffers start on 16-byte boundaries (float4 reads of dpool)
+    YMI_CHECK_ARG(((uintptr_t)workspace & 15) == 0, "cbam_bwd: workspace must be 16-byte aligned");
     float* du = reinterpret_cast<float*>(workspace);
-    float* dcap = du + NP;
-    float* dz = dcap + (int64_t)N * PB * C;
-    float* hsum = dz + (int64_t)N * C;
-    float* dpre = hsum + (int64_t)N * Hd;
-    float* dpool = dpre + (int64_t)2 * N * Hd;
+    float* dcap = du + up4(NP);
+    float* dz = dcap + up4((int64_t)N * PB * C);
+    float* hsum = dz + up4((int64_t)N * C);
+    float* dpre = hsum + up4((int64_t)N * Hd);
+    float* dpool = dpre + up4((int64_t)2 * N * Hd);
     hipStream_t s = (hipStream_t)stream;
     CV xv{x->data, x->ld}, dv{dout->data, dout->ld}, ov{dx->data, dx->ld};
     dim3 gw((unsigned)((NP + 3) / 4));
@@ -460,9 +503,9 @@ extern "C" int ymi_cbam_bwd(const ymi_tensor* x, const ymi_tensor* dout, const f
         hipLaunchKernelGGL(cbam_bwd_du_kernel<float>, gw, dim3(256), 0, s, xv, dv, NP, HW, C, ca, sa, du);
         hipLaunchKernelGGL(cbam_bwd_dx_kernel<float>, dim3(N * PB), dim3(256), 0, s, xv, dv, ov, N, H, W, C, ca, sa, du, smap_argmax, wsa, K, dcap, PB);
     }
-    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(N), dim3(256), lds3, s, dcap, PB, pooled, ca, w1, w2, C, Hd, dz, hsum, dpre, dpool);
-    hipLaunchKernelGGL(cbam_bwd_w_kernel, dim3((C * Hd + 255) / 256), dim3(256), 0, s, dz, hsum, dpre, pooled, N, C, Hd, dw1, dw2);
-    hipLaunchKernelGGL(cbam_bwd_wsa_kernel, dim3(2 * K * K), dim3(256), 0, s, du, smap, N, H, W, K, dwsa);
+    hipLaunchKernelGGL(cbam_bwd_mlp_kernel, dim3(N), dim3(1024), lds3, s, dcap, PB, pooled, ca, w1, w2, C, Hd, dz, hsum, dpre, dpool);
+    hipLaunchKernelGGL(cbam_bwd_w_kernel, dim3((2 * C * Hd + 255) / 256), dim3(256), 0, s, dz, hsum, dpre, pooled, N, C, Hd, dw1, dw2);
+    hipLaunchKernelGGL(cbam_bwd_wsa_kernel, dim3(2 * K * K), dim3(1024), 0, s, du, smap, N, H, W, K, dwsa);
     if (x->dtype == YMI_BF16) hipLaunchKernelGGL(cbam_bwd_pool_kernel<bf16_t>, dim3((unsigned)ge), dim3(256), 0, s, ov, NP, HW, C, dpool, pool_argmax);
     else hipLaunchKernelGGL(cbam_bwd_pool_kernel<float>, dim3((unsigned)ge), dim3(256), 0, s, ov, NP, HW, C, dpool, pool_argmax);
     YMI_CHECK_LAUNCH("cbam_bwd");

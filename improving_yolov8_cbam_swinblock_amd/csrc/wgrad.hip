@@ -447,7 +447,8 @@ static int wgrad_bm(int64_t coutp, bool bf16) {
 }
 static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm, size_t slab_esize) {
     const int64_t tiles = ((ng + WG_BN - 1) / WG_BN) * ((coutp + bm - 1) / bm);
-    static const int target64 = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;  // workgroups to aim for (tuning knobs)
+    // workgroups to aim for (tuning knobs; the in-situ optimum differs from the isolated one: see profiles/r03_wgrad_targets.txt)
+    static const int target64 = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1024;
     static const int target128 = getenv("YMI_WGRAD_BLOCKS128") ? atoi(getenv("YMI_WGRAD_BLOCKS128")) : 640;
     const int target = bm == 128 ? target128 : target64;
     int64_t s = (target + tiles - 1) / tiles;

@@ -768,14 +768,17 @@ class _ChanSlice(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        base = g._base
-        if (base is not None and tuple(base.shape) == ctx.shape and base.dtype == g.dtype and base.data_ptr() == g.data_ptr()
-                and base.stride() == g.stride() and getattr(base, "_ymi_zero_pad", False)):
+        base = _zero_padded.pop(g.data_ptr(), None)  # (python attributes do not survive the trip through the engine: keyed on the address)
+        if (base is not None and tuple(base.shape) == ctx.shape and base.dtype == g.dtype and base.stride() == g.stride()
+                and tuple(g.shape) == (ctx.shape[0], g.shape[1]) + ctx.shape[2:]):
             return base, None
         full = torch.zeros(ctx.shape, dtype=g.dtype, device=g.device).contiguous(memory_format=torch.channels_last) if len(ctx.shape) == 4 \
             else torch.zeros(ctx.shape, dtype=g.dtype, device=g.device)
         full[:, : g.shape[1]].copy_(g)
         return full, None
+
+
+_zero_padded = {}  # data_ptr -> padded buffer whose [:, :c] view padded_grad_like handed out (dropped when _ChanSlice.backward takes it)
 
 
 def padded_grad_like(t):
@@ -787,7 +790,9 @@ def padded_grad_like(t):
         if ld != c and ld % chunk_elems(t.dtype) == 0 and ld - c < chunk_elems(t.dtype):
             base = empty_nhwc(n, ld, h, w, t.dtype, t.device)
             base.zero_()
-            base._ymi_zero_pad = True
+            if len(_zero_padded) > 64:  # (gradients that never reached a _ChanSlice: do not keep their buffers alive)
+                _zero_padded.clear()
+            _zero_padded[base.data_ptr()] = base
             return base[:, :c]
     return torch.empty_like(t)
 
