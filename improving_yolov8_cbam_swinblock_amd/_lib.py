@@ -102,7 +102,7 @@ _SIGNATURES = {
     "ymi_detect_decode": (_c_i32, [_c_i32, _TP, _TP, ctypes.POINTER(ctypes.c_float), _vp, _vp]),
     "ymi_opt_chunk_elems": (_c_i64, []),
     "ymi_opt_grad_norm": (_c_i32, [_vp, _vp, _c_i32, _c_i32, _c_i64, ctypes.POINTER(_vp), _vp, _vp, _c_i64, _c_i64, _vp, _c_i32, _vp]),
-    "ymi_opt_update": (_c_i32, [_vp, _vp, _c_i32, _c_i32, _c_i64, ctypes.POINTER(_vp), _vp, _vp, _vp]),
+    "ymi_opt_update": (_c_i32, [_vp, _vp, _c_i32, _c_i32, _c_i64, ctypes.POINTER(_vp), _vp, _vp, _c_i32, _vp]),
 }
 
 OPT_MAX_GRADS = 448  # YMI_OPT_MAX_GRADS
@@ -114,7 +114,7 @@ class WgradPending(ctypes.Structure):
 
 
 class OptEntry(ctypes.Structure):
-    _fields_ = [("param", _vp), ("momentum", _vp), ("ema", _vp), ("numel", _c_i64), ("group", _c_i32), ("_pad", _c_i32)]
+    _fields_ = [("param", _vp), ("momentum", _vp), ("ema", _vp), ("numel", _c_i64), ("group", _c_i32), ("_pad", _c_i32), ("second", _vp), ("_pad2", _vp)]
 
 _lib = None
 _lock = threading.Lock()

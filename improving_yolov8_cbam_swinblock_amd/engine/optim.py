@@ -82,6 +82,8 @@ class ModelEMA:
 class FusedSGD:
     """SGD(momentum, nesterov) over the reference's three parameter groups + gradient clipping (+ EMA), fused."""
 
+    RULE = 0  # csrc/optim.hip hyper[14]: 0 SGD-momentum, 1 AdamW, 2 Adam
+
     def __init__(self, model, lr=0.01, momentum=0.937, decay=5e-4, nesterov=True, max_norm=10.0, ema=None, sgd=True):
         self.model = model
         g_bias, g_w, g_norm = param_groups_of(model) if sgd else ([], [], [])
@@ -95,6 +97,7 @@ class FusedSGD:
         self.world = 1  # gradients arrive already averaged over ranks (GradientBuckets.finish); hyper[11] = 1 / world stays 1
         self.ema = ema
         self.sgd = sgd
+        self._state = None
         self._table = None
         self._hyper_host = None
         self._keep = []
@@ -120,6 +123,11 @@ class FusedSGD:
                 self.momentum.append(buf)
                 e = ema_of.pop(p.data_ptr(), None)
                 entries.append((p, buf, e, gi))
+        old2 = dict(zip(old.keys(), getattr(self, "second", [])))
+        self.second = []  # Adam / AdamW: exp_avg_sq per parameter
+        if self.RULE:
+            for p in self.params:
+                self.second.append(old2[id(p)].to(p.device) if id(p) in old2 and old2[id(p)].shape == p.shape else torch.zeros_like(p))
         self.n_sgd = len(entries)
         # EMA-only entries: buffers (BN running statistics) and frozen parameters
         self.ema_only = []
@@ -136,7 +144,8 @@ class FusedSGD:
         cmap, self.ranges = [], []  # ranges: (first tensor, n tensors, first chunk, n chunks, has grads)
         first_chunk_of = []
         for i, (p, buf, e, gi) in enumerate(entries):
-            tab[i] = OptEntry(p.data_ptr(), buf.data_ptr() if buf is not None else None, e.data_ptr() if e is not None else None, p.numel(), gi, 0)
+            sec = self.second[i].data_ptr() if self.RULE and i < self.n_sgd else None
+            tab[i] = OptEntry(p.data_ptr(), buf.data_ptr() if buf is not None else None, e.data_ptr() if e is not None else None, p.numel(), gi, 0, sec, None)
             first_chunk_of.append(len(cmap))
             for c in range((p.numel() + chunk - 1) // chunk):
                 cmap.append((i, c))
@@ -152,9 +161,12 @@ class FusedSGD:
         self._cmap = torch.tensor(cmap, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
         self.n_grad_chunks = first_chunk_of[self.n_sgd] if self.sgd else len(cmap)
         self._partials = torch.zeros(max(self.n_grad_chunks, 1), dtype=torch.float32, device=dev)
-        self._state = torch.zeros(32, dtype=torch.uint8, device=dev)
+        steps = int(self._state.view(torch.int64)[3]) if getattr(self, "_state", None) is not None else 0  # rebuild: keep Adam's t
+        self._state = torch.zeros(64, dtype=torch.uint8, device=dev)
+        if steps:
+            self._state.view(torch.int64)[3] = steps
         self._dev_updates = 0  # host mirror of the device-side EMA update counter (_state[2]); see _sync_updates
-        self._hyper = torch.zeros(12, dtype=torch.float32, device=dev)
+        self._hyper = torch.zeros(20, dtype=torch.float32, device=dev)
         self._hyper_host = None  # a fresh device array: the next sync_hyper() must fill it
         self._ptrs = [p.data_ptr() for p, *_ in entries]
 
@@ -166,16 +178,24 @@ class FusedSGD:
         that captured step(); step() calls it itself)."""
         g = self.param_groups
         ema = self.ema
-        host = [g[0]["lr"], g[1]["lr"], g[2]["lr"], g[0]["weight_decay"], g[1]["weight_decay"], g[2]["weight_decay"], g[0]["momentum"],
-                self.max_norm, ema.decay_max if ema is not None else 0.0, ema.tau if ema is not None else 1.0, 1.0 if g[0]["nesterov"] else 0.0,
-                1.0 / self.world]
+        host = [g[0]["lr"], g[1]["lr"], g[2]["lr"], g[0]["weight_decay"], g[1]["weight_decay"], g[2]["weight_decay"], self._beta1(),
+                self.max_norm, ema.decay_max if ema is not None else 0.0, ema.tau if ema is not None else 1.0, 1.0 if g[0].get("nesterov") else 0.0,
+                1.0 / self.world, *self._rule_hyper(), 0.0, 0.0, 0.0]
         host = [float(v) for v in host]
-        if any(grp["momentum"] != g[0]["momentum"] or grp["nesterov"] != g[0]["nesterov"] for grp in g):
-            raise RuntimeError("FusedSGD: momentum / nesterov are shared by the three groups (as the reference sets them)")
         if host != self._hyper_host:
             self._hyper.copy_(torch.tensor(host, dtype=torch.float32))
             self._hyper_host = host
         self._sync_updates()
+
+    def _beta1(self):
+        g = self.param_groups
+        if any(grp["momentum"] != g[0]["momentum"] or grp["nesterov"] != g[0]["nesterov"] for grp in g):
+            raise RuntimeError("FusedSGD: momentum / nesterov are shared by the three groups (as the reference sets them)")
+        return g[0]["momentum"]
+
+    def _rule_hyper(self):
+        """hyper[12..16]: beta2, eps, rule, 1 - beta2, 1 - beta1."""
+        return 0.0, 0.0, float(self.RULE), 0.0, 0.0
 
     def _sync_updates(self):
         """the kernel derives the EMA decay from a DEVICE counter; `ema.updates` is the host's view of it.  A caller may set
@@ -229,7 +249,7 @@ class FusedSGD:
         for i, (first, n, c0, nc, has) in enumerate(self.ranges):
             if nc:
                 check(L.ymi_opt_update(tab, ctypes.c_void_p(cmap.data_ptr() + c0 * 8), first, n, nc, grad_arrays[i] if has else None,
-                                       ctypes.c_void_p(self._hyper.data_ptr()), ctypes.c_void_p(self._state.data_ptr()), st), "opt_update")
+                                       ctypes.c_void_p(self._hyper.data_ptr()), ctypes.c_void_p(self._state.data_ptr()), int(self.RULE), st), "opt_update")
         self._keep.clear()
         if self.ema is not None:
             self.ema.updates += 1
@@ -272,3 +292,69 @@ class FusedSGD:
             buf = st.get("momentum_buffer")
             if buf is not None:
                 self.momentum[int(idx)].copy_(buf.to(self.momentum[int(idx)].dtype))
+
+
+class FusedAdamW(FusedSGD):
+    """torch.optim.AdamW over the reference's three parameter groups (trainer.py:829-830 `optim.AdamW(g[2], lr=lr,
+    betas=(momentum, 0.999), weight_decay=0.0)` + the two add_param_group calls; what optimizer='auto' picks for runs of at most
+    10000 iterations, :812) + gradient clipping (+ EMA), in the same three launches as FusedSGD.  `decoupled=False` is
+    torch.optim.Adam (weight decay added to the gradient).  `param_groups` carry torch's Adam keys (lr, betas, eps, weight_decay);
+    state_dict() / load_state_dict() use torch.optim.Adam's layout (step, exp_avg, exp_avg_sq per parameter)."""
+
+    RULE = 1
+
+    def __init__(self, model, lr=0.001, betas=(0.9, 0.999), eps=1e-8, decay=5e-4, max_norm=10.0, ema=None, decoupled=True):
+        super().__init__(model, lr=lr, momentum=betas[0], decay=decay, nesterov=False, max_norm=max_norm, ema=ema)
+        self.RULE = 1 if decoupled else 2
+        for grp in self.param_groups:
+            for k in ("momentum", "nesterov", "dampening"):
+                grp.pop(k)
+            grp.update(betas=(float(betas[0]), float(betas[1])), eps=float(eps), amsgrad=False)
+
+    def _beta1(self):
+        g = self.param_groups
+        if any(tuple(grp["betas"]) != tuple(g[0]["betas"]) or grp["eps"] != g[0]["eps"] for grp in g):
+            raise RuntimeError("FusedAdamW: betas / eps are shared by the three groups (as the reference sets them)")
+        return g[0]["betas"][0]
+
+    def _rule_hyper(self):
+        g = self.param_groups[0]
+        return g["betas"][1], g["eps"], float(self.RULE), 1 - g["betas"][1], 1 - g["betas"][0]
+
+    @property
+    def exp_avg(self):
+        return self.momentum
+
+    def steps_taken(self):
+        """Adam's t (one device->host read)."""
+        return int(self._state.view(torch.int64)[3]) if self._table is not None else 0
+
+    def state_dict(self):
+        if self._table is None:
+            self._build()
+        t = float(self.steps_taken())
+        state, groups, idx = {}, [], 0
+        for grp in self.param_groups:
+            ids = []
+            for p in grp["params"]:
+                if t > 0 and p.requires_grad:  # torch creates a parameter's state at its first step with a gradient
+                    state[idx] = {"step": torch.tensor(t), "exp_avg": self.momentum[idx], "exp_avg_sq": self.second[idx]}
+                ids.append(idx)
+                idx += 1
+            groups.append({k: v for k, v in grp.items() if k != "params"} | {"params": ids, "maximize": False, "foreach": None, "capturable": False,
+                                                                             "differentiable": False, "fused": None, "decoupled_weight_decay": self.RULE == 1})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        if self._table is None:
+            self._build()
+        for grp, saved in zip(self.param_groups, sd["param_groups"]):
+            for k in ("lr", "initial_lr", "betas", "eps", "weight_decay"):
+                if k in saved:
+                    grp[k] = tuple(saved[k]) if k == "betas" else saved[k]
+        steps = 0
+        for idx, st in sd["state"].items():
+            self.momentum[int(idx)].copy_(st["exp_avg"].to(torch.float32))
+            self.second[int(idx)].copy_(st["exp_avg_sq"].to(torch.float32))
+            steps = max(steps, int(float(st["step"])))
+        self._state.view(torch.int64)[3] = steps  # one t for every parameter (they step together)

@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import ops
 from .ddp import GradientBuckets
-from .optim import FusedSGD, ModelEMA
+from .optim import FusedAdamW, FusedSGD, ModelEMA
 
 # weight-gradient GEMMs on a second stream during backward (ops.async_wgrad) in EAGER steps; YMI_WGRAD_STREAM=0 keeps
 # one stream.  Graph-replayed steps stay single-stream: measured no wall-time gain there, and concurrent kernels stretch
@@ -16,12 +16,28 @@ from .optim import FusedSGD, ModelEMA
 ASYNC_WGRAD = os.environ.get("YMI_WGRAD_STREAM", "1") != "0"
 
 
-def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, ema=None):
-    """reference build_optimizer (trainer.py:788-849, 'SGD' branch :832-833) + optimizer_step's clip (:617): three
-    parameter groups, nesterov momentum, weight decay on the weights only - as the fused HIP step (engine/optim.py).
-    The gradients it is handed are already the mean over ranks (GradientBuckets.finish divides once), so the step itself
+def build_optimizer(model, name="SGD", lr=0.01, momentum=0.937, decay=5e-4, ema=None, iterations=1e5, nc=None):
+    """reference build_optimizer (trainer.py:788-849) + optimizer_step's clip (:617): three parameter groups (biases, decayed
+    weights, norm weights) and
+      * 'SGD'  (:832-833)  nesterov momentum, as the fused HIP step FusedSGD;
+      * 'AdamW' / 'Adam' (:829-830)  betas = (momentum, 0.999), as FusedAdamW;
+      * 'auto' (:804-813)  SGD(lr 0.01, momentum 0.9) for more than 10000 iterations, else AdamW(lr = round(0.002 * 5 / (4 + nc), 6),
+        beta1 0.9) - the caller's lr / momentum are ignored, as in the reference.
+    The reference's other names (Adamax, NAdam, RAdam, RMSProp) have no fused step here and raise NotImplementedError.
+    The gradients the step is handed are already the mean over ranks (GradientBuckets.finish divides once), so the step itself
     never scales by the world size."""
-    return FusedSGD(model, lr=lr, momentum=momentum, decay=decay, nesterov=True, max_norm=10.0, ema=ema)
+    if name == "auto":
+        if nc is None:
+            nc = getattr(model, "nc", None) or getattr(model.model[-1], "nc", 10)
+        lr_fit = round(0.002 * 5 / (4 + nc), 6)
+        name, lr, momentum = ("SGD", 0.01, 0.9) if iterations > 10000 else ("AdamW", lr_fit, 0.9)
+    known = {x.lower(): x for x in ("Adam", "Adamax", "AdamW", "NAdam", "RAdam", "RMSProp", "SGD")}
+    name = known.get(str(name).lower())
+    if name == "SGD":
+        return FusedSGD(model, lr=lr, momentum=momentum, decay=decay, nesterov=True, max_norm=10.0, ema=ema)
+    if name in ("AdamW", "Adam"):
+        return FusedAdamW(model, lr=lr, betas=(momentum, 0.999), decay=decay, max_norm=10.0, ema=ema, decoupled=name == "AdamW")
+    raise NotImplementedError(f"optimizer {name!r}: the fused MI355X step implements SGD, AdamW and Adam (reference trainer.py:827-840)")
 
 
 def synthetic_batch(batch, imgsz, device, seed, boxes_per_image=4):
@@ -59,12 +75,13 @@ class TrainStep:
     later eager cat/stack rewrites it), so the replayed cat reads wrong pointers: silently wrong values, or a memory
     fault.  The captured step contains only kernels of this library and elementwise ATen ops."""
 
-    def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20, graph=False, ema=True):
+    def __init__(self, model, world_size=1, lr=0.01, dtype=torch.bfloat16, bucket_bytes=32 << 20, graph=False, ema=True, optimizer="SGD",
+                 momentum=0.937, decay=5e-4):
         self.model = model
         self.world = world_size
         self.dtype = dtype
         self.ema = ModelEMA(model) if ema is True else (ema or None)
-        self.opt = build_optimizer(model, lr=lr, ema=self.ema)
+        self.opt = build_optimizer(model, name=optimizer, lr=lr, momentum=momentum, decay=decay, ema=self.ema)
         self.use_graph = bool(graph)
         self.full_graph = self.use_graph and world_size == 1 and graph != "split"  # graph="split": the multi-rank form on one rank
         self.buckets = GradientBuckets(model, world_size, bucket_bytes, overlap=not self.use_graph)

@@ -1,6 +1,6 @@
 """ORACLE (test infrastructure): CPU restatement of the reference's optimizer step in plain torch ops.
 
-reference: ultralytics/engine/trainer.py:788-849 (build_optimizer, 'SGD' branch), :614-622 (optimizer_step) and
+reference: ultralytics/engine/trainer.py:788-849 (build_optimizer, 'SGD' and 'AdamW' / 'Adam' branches), :614-622 (optimizer_step) and
 ultralytics/utils/torch_utils.py:620-673 (ModelEMA).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
 may import this package; the product never does.
 """
@@ -11,8 +11,9 @@ import torch
 import torch.nn as nn
 
 
-def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
-    """trainer.py:814-843: g[2] biases (no decay) first, then add_param_group(g[0] weights, decay), (g[1] norm weights)."""
+def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, name="SGD"):
+    """trainer.py:814-843: g[2] biases (no decay) first, then add_param_group(g[0] weights, decay), (g[1] norm weights);
+    name: 'SGD' (:832-833) or 'AdamW' / 'Adam' (:829-830, betas = (momentum, 0.999))."""
     g = [], [], []  # frozen parameters ('.dfl', trainer.py:244-256) are grouped too: SGD skips tensors without a gradient
     bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
     for module_name, module in model.named_modules():
@@ -24,7 +25,10 @@ def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4):
                 g[1].append(param)
             else:
                 g[0].append(param)
-    opt = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
+    if name in ("AdamW", "Adam"):
+        opt = getattr(torch.optim, name)(g[2], lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+    else:
+        opt = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
     opt.add_param_group({"params": g[0], "weight_decay": decay})
     opt.add_param_group({"params": g[1], "weight_decay": 0.0})
     return opt

@@ -301,7 +301,7 @@ def swin_large_fixtures():
         save(name, **arrays)
 
 
-def opt_step_fixture():
+def opt_step_fixture(opt_name="SGD", lr=0.01, momentum=0.937, out_name="opt_step_tiny"):
     """two optimizer steps of the REAL reference trainer code on the width-reduced model of e2e_tiny: BaseTrainer.build_optimizer
     ('SGD' branch, trainer.py:788-849), optimizer_step's clip + step + zero_grad (trainer.py:614-622, GradScaler disabled as
     for fp32 / bf16) and ModelEMA.update (torch_utils.py:657-673).  Stored: group membership, gradient norms, and strided
@@ -325,14 +325,15 @@ def opt_step_fixture():
         if ".dfl" in k:
             v.requires_grad = False
     fake = SimpleNamespace(args=SimpleNamespace(lr0=0.01, momentum=0.937, warmup_bias_lr=0.1), data={"nc": 1})
-    opt = BaseTrainer.build_optimizer(fake, model, name="SGD", lr=0.01, momentum=0.937, decay=5e-4)
+    opt = BaseTrainer.build_optimizer(fake, model, name=opt_name, lr=lr, momentum=momentum, decay=5e-4)
     ema = ModelEMA(model)
     batch = {"img": torch.from_numpy(z["img"]), "batch_idx": torch.from_numpy(z["batch_idx"]), "cls": torch.from_numpy(z["cls"]),
              "bboxes": torch.from_numpy(z["bboxes"])}
     names = {id(p): n for n, p in model.named_parameters()}
     arrays = {}
     meta = {"groups": [[names[id(p)] for p in g["params"]] for g in opt.param_groups],
-            "group_hyper": [{k: g[k] for k in ("lr", "momentum", "weight_decay", "nesterov")} for g in opt.param_groups], "norms": [], "loss": []}
+            "group_hyper": [{k: (list(g[k]) if isinstance(g[k], tuple) else g[k]) for k in ("lr", "momentum", "weight_decay", "nesterov", "betas", "eps") if k in g}
+                            for g in opt.param_groups], "norms": [], "loss": [], "optimizer": type(opt).__name__}
     model.train()
     crit = v8DetectionLoss(model)
     for step in range(2):
@@ -353,8 +354,8 @@ def opt_step_fixture():
                 for kind, v in grad_record(p).items():
                     arrays[f"s{step}.e{kind}.{n}"] = v
     meta["ema_updates"] = ema.updates
-    save("opt_step_tiny", **arrays)
-    (OUT / "opt_step_tiny.json").write_text(json.dumps(meta))
+    save(out_name, **arrays)
+    (OUT / f"{out_name}.json").write_text(json.dumps(meta))
 
 
 def tie_fixtures():
@@ -406,8 +407,11 @@ if __name__ == "__main__":
         swin_large_fixtures()
     elif len(sys.argv) > 1 and sys.argv[1] == "opt_step":
         opt_step_fixture()
+    elif len(sys.argv) > 1 and sys.argv[1] == "opt_step_adamw":  # the 'AdamW' branch (what optimizer='auto' picks for short runs)
+        opt_step_fixture("AdamW", lr=0.002, momentum=0.9, out_name="opt_step_tiny_adamw")
     else:
         main()
         swin_large_fixtures()
         opt_step_fixture()
+        opt_step_fixture("AdamW", lr=0.002, momentum=0.9, out_name="opt_step_tiny_adamw")
         tie_fixtures()
