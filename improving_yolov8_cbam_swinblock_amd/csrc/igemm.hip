@@ -809,8 +809,7 @@ struct TileChoice {
 static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool bf16) {
     TileChoice t;
     auto blocks = [&](int bm, int bn) { return ((M + bm - 1) / bm) * ((cout + bn - 1) / bn); };
-    static const int enough_env = getenv("YMI_IGEMM_ENOUGH") ? atoi(getenv("YMI_IGEMM_ENOUGH")) : 400;  // tuning knob
-    const int64_t enough = enough_env;
+    const int64_t enough = 400;
     if (cout <= 32) {
         t.bm = 128; t.bn = 32;
     } else if (cout <= 64) {
@@ -827,8 +826,8 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool bf16) 
     // ping-pong form of the 256x128 tile (the two 128-row halves half a K step apart), where it leaves >= `pp_env` workgroups.
     // Default from 300 workgroups (measured, profiles/r02_conv_bench_pp64.txt: 64-byte rows - three 24 KB stages, TWO resident
     // workgroups per CU - win 5-19 % on every layer that yields >= 400 such tiles and lose 15-25 % at 200; step 14.71 -> 14.38 ms).
-    static const int pp_env = getenv("YMI_IGEMM_PP") ? atoi(getenv("YMI_IGEMM_PP")) : 300;  // tuning knob (0: off)
-    if (pp_env > 0 && bf16 && cout >= 128 && ktot % 32 == 0 && blocks(256, 128) >= pp_env) {
+    constexpr int pp_env = 300;
+    if (bf16 && cout >= 128 && ktot % 32 == 0 && blocks(256, 128) >= pp_env) {
         t.bm = 256; t.bn = 128; t.pp = true;
     }
     static const char* tile_env = getenv("YMI_IGEMM_TILE");  // "bm,bn": force a tile (tools/conv_bench.py sweeps)

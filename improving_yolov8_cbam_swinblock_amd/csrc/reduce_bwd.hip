@@ -322,10 +322,7 @@ static int launch_bn_apply(const ymi_tensor* dout, const ymi_tensor* raw, const 
     const int64_t P = ymi_pixels(dout);
     const int C = (int)dout->c;
     const bool bf = dout->dtype == YMI_BF16;
-    const bool al16 = bf && C % 8 == 0 && dout->ld % 8 == 0 && raw->ld % 8 == 0 && draw->ld % 8 == 0 &&
-                      (((uintptr_t)dout->data | (uintptr_t)raw->data | (uintptr_t)draw->data) & 15) == 0;
-    static const int g8_env = getenv("YMI_BN_APPLY8") ? atoi(getenv("YMI_BN_APPLY8")) : 0;  // tuning knob: 1 = 16-byte (8-channel) groups for bf16; measured equal to the 8-byte form
-    const int G = (al16 && g8_env && C / 8 <= 256 && 256 % (C / 8) == 0) ? 8 : 4;
+    const int G = 4;  // 8-byte (bf16) / 16-byte (f32) channel groups (16-byte groups for bf16 measured equal in round 2: removed)
     const int groups = C / G;
     const bool fixed = groups <= 256 && 256 % groups == 0;
     const int64_t total = P * groups;
@@ -349,8 +346,7 @@ static int launch_bn_apply(const ymi_tensor* dout, const ymi_tensor* raw, const 
         else YMI_BWD_APPLY(T, GG, F, YMI_ACT_NONE);                         \
     } while (0)
     if (bf) {
-        if (G == 8) YMI_BWD_APPLY_A(bf16_t, 8, true);
-        else if (fixed) YMI_BWD_APPLY_A(bf16_t, 4, true);
+        if (fixed) YMI_BWD_APPLY_A(bf16_t, 4, true);
         else YMI_BWD_APPLY_A(bf16_t, 4, false);
     } else {
         if (fixed) YMI_BWD_APPLY_A(float, 4, true);

@@ -36,11 +36,5 @@ const void* ymi_zero_page() {
     return cached_ptr;
 }
 
-int ew_ppt() {
-    static const int v = getenv("YMI_EW_PPT") ? atoi(getenv("YMI_EW_PPT")) : 8;
-    return v > 0 ? v : 8;
-}
-int ew_cap() {
-    static const int v = getenv("YMI_EW_CAP") ? atoi(getenv("YMI_EW_CAP")) : 2048;
-    return v > 0 ? v : 2048;
-}
+int ew_ppt() { return 8; }     // pixels per thread the elementwise passes aim for (round-1 sweep)
+int ew_cap() { return 2048; }  // their workgroup cap

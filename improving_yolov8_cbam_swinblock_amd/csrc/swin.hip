@@ -1144,7 +1144,6 @@ extern "C" int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int
     YMI_CHECK_ARG(ymi_tensor_ok(out) && out->c == a.C && ymi_pixels(out) == ymi_pixels(qkv) && out->dtype == qkv->dtype, "window_attention_fwd: out");
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.lse = lse;
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
-    static const int attn_tr = getenv("YMI_ATTN_TR") ? atoi(getenv("YMI_ATTN_TR")) : 1;  // 0: the generic (f32-style) kernel for bf16 too
     static const int attn_tiled = getenv("YMI_ATTN_TILED") ? atoi(getenv("YMI_ATTN_TILED")) : 0;  // 1: tiled kernels for every window size (tests)
     const size_t lds_tr = (size_t)3 * 64 * (a.hdp + 8) * 2 + (size_t)64 * (64 + 8) * 2;
     if (wlen > 64 || lds > 160 * 1024 || attn_tiled) {
@@ -1156,7 +1155,7 @@ extern "C" int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_tiled_fwd_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             hipLaunchKernelGGL(window_attn_tiled_fwd_kernel<float>, tg, dim3(256), tiled_lds<float>(false), (hipStream_t)stream, a);
         }
-    } else if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
+    } else if (qkv->dtype == YMI_BF16 && lds_tr <= 160 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_fwd_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_fwd_tr_kernel, grid, dim3(256), lds_tr, (hipStream_t)stream, a);
     } else if (qkv->dtype == YMI_BF16) {
@@ -1183,7 +1182,6 @@ extern "C" int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor*
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.dout = SV{dout->data, dout->ld}; a.dqkv = SV{dqkv->data, dqkv->ld};
     a.lse = const_cast<float*>(lse);
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
-    static const int attn_tr = getenv("YMI_ATTN_TR") ? atoi(getenv("YMI_ATTN_TR")) : 1;  // 0: the generic (f32-style) kernel for bf16 too
     static const int attn_tiled = getenv("YMI_ATTN_TILED") ? atoi(getenv("YMI_ATTN_TILED")) : 0;
     const size_t lds_tr = (size_t)4 * 64 * (a.hdp + 8) * 2 + (size_t)2 * 64 * (64 + 8) * 2;
     if (wlen > 64 || lds > 160 * 1024 || attn_tiled) {
@@ -1198,7 +1196,7 @@ extern "C" int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor*
         if (qkv->dtype == YMI_BF16) YMI_TILED_BWD(bf16_t);
         else YMI_TILED_BWD(float);
 #undef YMI_TILED_BWD
-    } else if (qkv->dtype == YMI_BF16 && attn_tr && lds_tr <= 160 * 1024) {
+    } else if (qkv->dtype == YMI_BF16 && lds_tr <= 160 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(window_attn_bwd_tr_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         hipLaunchKernelGGL(window_attn_bwd_tr_kernel, grid, dim3(256), lds_tr, (hipStream_t)stream, a);
     } else if (qkv->dtype == YMI_BF16) {
