@@ -79,16 +79,21 @@ template <typename T> struct WFrag;
 // bit 0 of the unit index, so it is a permutation of 16-byte chunks and can be applied to the LDS-DMA SOURCE address.
 __device__ __forceinline__ int wg_swz_y(int row) { return ((row >> 1) & 1) | (((row >> 3) & 1) << 1); }        // 2 bits
 __device__ __forceinline__ int wg_swz_x(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }                // 3 bits
+// 64-byte rows (the dY image of the 32-channel tile): rows r and r+8 of a half share banks, rows r..r+3 do not: one bit
+__device__ __forceinline__ int wg_swz_y32(int row) { return (row >> 3) & 1; }
+// swizzle mode of an LDS image by its row width: 0 = 128-byte rows, 1 = 256-byte (and wider) rows, 2 = 64-byte rows
+template <int SW> __device__ __forceinline__ int wg_swz(int row) { return SW == 1 ? wg_swz_x(row) : SW == 2 ? wg_swz_y32(row) : wg_swz_y(row); }
+template <int BM> struct YSwz { static constexpr int SW = BM == 128 ? 1 : BM == 32 ? 2 : 0; };
 
 template <> struct WFrag<bf16_t> {
     // fragment of 8 k-values (pixels 8g..8g+7) for column c0+i of a [pixel][col] LDS image with `rowb` bytes per row
-    template <bool XIMG>
+    template <int SW>
     static __device__ __forceinline__ bf16x8 load(const char* img, int rowb, int c0, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
         const int r_lo = 8 * g + q, r_hi = r_lo + 4;
         const int u = (c0 >> 2) + p;  // logical 8-byte unit of this lane's 4 columns
-        const int u_lo = u ^ ((XIMG ? wg_swz_x(r_lo) : wg_swz_y(r_lo)) << 2);
-        const int u_hi = u ^ ((XIMG ? wg_swz_x(r_hi) : wg_swz_y(r_hi)) << 2);
+        const int u_lo = u ^ (wg_swz<SW>(r_lo) << 2);
+        const int u_hi = u ^ (wg_swz<SW>(r_hi) << 2);
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + r_lo * rowb + u_lo * 8));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + r_hi * rowb + u_hi * 8));
         typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -103,11 +108,11 @@ template <> struct WFrag<bf16_t> {
             const char* Xk = Xs + ks * 32 * BNW * 2;
             bf16x8 af[TR], bfr[TC];
 #pragma unroll
-            for (int t = 0; t < TR; ++t) af[t] = load<(BM == 128)>(Yk, BM * 2, r0 + t * 16, lane);  // 256-byte dY rows use the X swizzle
+            for (int t = 0; t < TR; ++t) af[t] = load<YSwz<BM>::SW>(Yk, BM * 2, r0 + t * 16, lane);  // by the dY image's row width
             // (512-byte X rows of the 256-column tile: the XOR only touches the low five bits of the 8-byte unit index, i.e. it
             // permutes units inside each 256-byte bank row exactly as for 256-byte rows)
 #pragma unroll
-            for (int t = 0; t < TC; ++t) bfr[t] = load<true>(Xk, BNW * 2, c0 + t * 16, lane);
+            for (int t = 0; t < TC; ++t) bfr[t] = load<1>(Xk, BNW * 2, c0 + t * 16, lane);
 #pragma unroll
             for (int a = 0; a < TR; ++a)
 #pragma unroll
@@ -136,7 +141,9 @@ template <> struct WFrag<float> {
 };
 
 // BM = output channels per workgroup tile: 64, or 128 for layers with >= 128 output channels (16 instead of 8 MFMAs per
-// wave and K step against the same address arithmetic: the K loop is instruction-issue-bound, not MFMA-bound)
+// wave and K step against the same address arithmetic: the K loop is instruction-issue-bound, not MFMA-bound), or 32 for the
+// layers with <= 32 output channels (the 320x320 / 160x160 maps: millions of pixels against a 32 x 72..288 weight matrix; the
+// 64-row tile spent half its MFMAs on padding rows)
 // (a 128x256 tile - 4 or 8 waves - measured 1.17-1.66x slower, profiles/r02_conv_bench_wgrad256.txt; removed in round 3)
 template <typename T, int NS, int BM>
 __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
@@ -144,7 +151,10 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
     constexpr int YCW = BM * ES / 16, XCW = BNW * ES / 16;            // 16-byte chunks per tile row
-    constexpr int NY = WG_BK * YCW / NT, NX = WG_BK * XCW / NT;       // chunks per thread per K step
+    constexpr int YT = WG_BK * YCW < NT ? WG_BK * YCW : NT;           // threads that cover one dY load of the workgroup (32-channel tile: 128 -
+                                                                      // the other two waves fetch the SAME chunks to the SAME LDS bytes, so every
+                                                                      // wave issues the same number of loads and the counted waits stay uniform)
+    constexpr int NY = (WG_BK * YCW + NT - 1) / NT, NX = WG_BK * XCW / NT;  // chunks per thread per K step
     constexpr int WCOLS = BNW / 64, WROWS = (NT / 64) / WCOLS;        // wave grid: every wave owns a (BM / WROWS) x 64 tile
     constexpr int YBYTES = WG_BK * BM * ES, XBYTES = WG_BK * BNW * ES;
     constexpr int STAGE = YBYTES + XBYTES;
@@ -182,7 +192,8 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     // dY loader: thread -> (row, chunk) ; chunk column fixed per thread.  bf16: LDS position (row, chunk') holds
     // source chunk chunk' ^ (swizzle(row) << 1); the row bits the swizzle uses are the same for all of a thread's rows.
     constexpr bool SWZ = std::is_same<T, bf16_t>::value;
-    const int ycc = SWZ ? ((tid % YCW) ^ ((BM == 128 ? wg_swz_x(tid / YCW) : wg_swz_y(tid / YCW)) << 1)) : (tid % YCW);
+    const int ytid = tid % YT;
+    const int ycc = SWZ ? ((ytid % YCW) ^ (wg_swz<YSwz<BM>::SW>(ytid / YCW) << 1)) : (ytid % YCW);
     const bool y_cok = co0 + ycc * CH < a.CoutP;
     // X loader: column chunk fixed per thread -> fixed tap / input-channel offset
     static_assert(NT / XCW >= 16 || !std::is_same<T, bf16_t>::value, "bf16: a block-wide load covers >= 16 rows, so a thread's rows share the row bits the swizzle uses");
@@ -226,7 +237,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     uint32_t y_off[NY];
 #pragma unroll
     for (int i = 0; i < NY; ++i) {
-        y_row[i] = tid / YCW + i * (NT / YCW);
+        y_row[i] = ytid / YCW + i * (NT / YCW);
         y_off[i] = (uint32_t)((m_begin + y_row[i]) * ldy32 + co0 + ycc * CH);
     }
     const uint32_t y_step = (uint32_t)(WG_BK * ldy32);
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         for (int i = 0; i < NY; ++i) {
             const bool ok = y_cok && y_row[i] < left;
             const T* src = ok ? yg + y_off[i] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * NT + wave * 64) * 16), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * NT + (wave * 64) % YT) * 16), 16, 0, 0);
             y_off[i] += y_step;
         }
 #pragma unroll
@@ -443,6 +454,7 @@ struct WgradPlan {
 // per wave and K step) it is 7-12 % faster on every layer with >= 128 output channels.
 static int wgrad_bm(int64_t coutp, bool bf16) {
     if (!bf16) return 64;
+    if (coutp <= 32) return 32;
     return (coutp >= 128 && coutp % 128 == 0) || coutp >= 256 ? 128 : 64;
 }
 static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm, size_t slab_esize) {
@@ -568,6 +580,7 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     if (bf16) {
         // two LDS stages (deeper rings measured equal: same bytes in flight per CU)
         if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
+        else if (bm == 32) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 32>), grid, dim3(256), (size_t)2 * (WG_BK * (32 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
         else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 64>), grid, dim3(256), (size_t)2 * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
     } else {
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
