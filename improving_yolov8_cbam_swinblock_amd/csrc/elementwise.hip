@@ -306,6 +306,14 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s1 = 0.0, s2 = 0.0;
+    // parameters and running statistics are fetched first, beside the partials (a chain of load latencies otherwise)
+    float g_ = 1.0f, b_ = 0.0f, rm_ = 0.f, rv_ = 0.f;
+    if (slice == 0 && c < C) {
+        if (gamma) g_ = gamma[c];
+        if (beta) b_ = beta[c];
+        if (rmean) rm_ = rmean[c];
+        if (rvar) rv_ = rvar[c];
+    }
     if (c < C) {
         // four independent chains per sum: the loads of a trip are all in flight before the first add
         float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
@@ -342,16 +350,16 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         double var = s2 / count - mean * mean;
         if (var < 0.0) var = 0.0;
         const float inv = (float)(1.0 / sqrt(var + (double)eps));
-        const float g = gamma ? gamma[c] : 1.0f, b = beta ? beta[c] : 0.0f;
+        const float g = g_, b = b_;
         const float sc = g * inv;
         scale[c] = sc;
         shift[c] = b - (float)mean * sc;
         if (smean) smean[c] = (float)mean;
         if (sinv) sinv[c] = inv;
-        if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * (float)mean;
+        if (rmean) rmean[c] = (1.0f - momentum) * rm_ + momentum * (float)mean;
         if (rvar) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (float)unb;
+            rvar[c] = (1.0f - momentum) * rv_ + momentum * (float)unb;
         }
     }
 }

@@ -121,6 +121,15 @@ __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
     double s0 = 0.0, s1 = 0.0;
+    // the per-channel parameters of the coefficient pass are fetched FIRST, beside the partials (this kernel is a chain of load
+    // latencies: behind the barrier they were a round trip of their own)
+    float ga = 1.0f, be = 0.0f, p_inv = 0.f, p_mean = 0.f;
+    if (slice == 0 && c < C && bn.coef) {
+        ga = bn.gamma ? bn.gamma[c] : 1.0f;
+        be = bn.beta ? bn.beta[c] : 0.0f;
+        p_inv = bn.inv[c];
+        p_mean = bn.mean[c];
+    }
     if (c < C) {
         float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
         int b = slice;
@@ -154,8 +163,7 @@ __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __
         if (out0) out0[c] = (float)a;
         if (out1) out1[c] = (float)b2;
         if (bn.coef) {
-            const float ga = bn.gamma ? bn.gamma[c] : 1.0f, be = bn.beta ? bn.beta[c] : 0.0f;
-            const float p0 = bn.inv[c], p1 = -bn.mean[c] * p0;
+            const float p0 = p_inv, p1 = -p_mean * p0;
             const float k1 = (float)a * bn.inv_count, k2 = (float)b2 * bn.inv_count;
             bn.coef[0 * C + c] = p0 * ga;
             bn.coef[1 * C + c] = p1 * ga + be;

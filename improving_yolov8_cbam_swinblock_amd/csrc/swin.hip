@@ -737,6 +737,14 @@ __global__ __launch_bounds__(256) void window_attn_bwd_tr_kernel(AttnArgs a) {
     T* dqkv = reinterpret_cast<T*>(const_cast<void*>(a.dqkv.p)) + t0 * a.dqkv.ld;
     const int ndt = (a.hd + 15) / 16;
 
+    // the saved log-sum-exp of this lane's four query rows: requested before the operand staging (it was a dependent global round
+    // trip between the first MFMAs and the softmax)
+    float lse4[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int m = 16 * wv + 4 * l4 + r;
+        lse4[r] = m < L ? a.lse[(t0 + m) * a.heads + head] : 0.f;
+    }
     {
         const bf16_t* srcs[4] = {qkv + co, qkv + a.C + co, qkv + 2 * a.C + co, dO + co};
         const int64_t lds_[4] = {a.qkv.ld, a.qkv.ld, a.qkv.ld, a.dout.ld};
@@ -758,7 +766,7 @@ __global__ __launch_bounds__(256) void window_attn_bwd_tr_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int m = 16 * wv + 4 * l4 + r;
-        const float lse = m < L ? a.lse[(t0 + m) * a.heads + head] : 0.f;
+        const float lse = lse4[r];
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
             const bool ok = (16 * t + l15 < L) && (m < L);

@@ -338,6 +338,33 @@ class DetectionModel(BaseModel):
         outs = self._channel_trace(self.yaml["ch"])
         return [float(s[1]) for s in outs[-1]]
 
+    @torch.no_grad()
+    def stride_probe(self, s=256):
+        """Reproduce the SIDE EFFECTS of the reference's construction-time stride probe (tasks.py:351-364): one train-mode forward
+        of zeros(1, ch, s, s), run BEFORE initialize_weights (:367) sets BatchNorm's eps = 1e-3 / momentum = 0.03 - i.e. with
+        nn.BatchNorm2d's defaults eps = 1e-5, momentum = 0.1.  It leaves every BatchNorm of a freshly built reference model with
+        running_var = 0.9 + 0.1 * (unbiased batch variance of that forward), running_mean = 0.1 * (batch mean) and
+        num_batches_tracked = 1 (ahead of the first SwinBlock all activations are zero, so there running_var = 0.9 exactly).
+        Here the strides come from the graph and construction touches no buffer; call this once, with the model on the GPU, to
+        get the reference's buffers (tests/test_gpu_e2e_golden.py::test_stride_probe_side_effects_match_the_reference).
+        Returns the measured strides, which equal self.stride."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("stride_probe runs the libyolo_mi355 kernels: move the model to the MI355X (cuda) device first; there is no CPU path")
+        bns = [m for m in self.modules() if isinstance(m, nn.BatchNorm2d)]
+        saved = [(m.eps, m.momentum) for m in bns]
+        was_training = self.training
+        try:
+            for m in bns:
+                m.eps, m.momentum = 1e-5, 0.1
+            self.train()
+            outs = self.forward(torch.zeros(1, self.yaml["ch"], s, s, device=dev))
+        finally:
+            for m, (eps, mom) in zip(bns, saved):
+                m.eps, m.momentum = eps, mom
+            self.train(was_training)
+        return torch.tensor([s / o.shape[-2] for o in outs], dtype=torch.float32)
+
     def init_criterion(self):
         return v8DetectionLoss(self)
 
