@@ -332,13 +332,35 @@ __global__ __launch_bounds__(256) void topk_kernel(LossGeom g, const float* __re
     if (!((gt[0] + gt[1] + gt[2] + gt[3]) > 0.f)) return;  // padding row: selects nothing (uniform across the block)
     const float* row = al + (int64_t)bg * g.A;
     Best prev{__builtin_inff(), -1};
+    // the gt's metric row is read ONCE into registers when it fits (A <= 256 * TOPK_NV: 8400 anchors at 640x640 are 33 values per
+    // thread); the k selection rounds then only scan registers.  (Ten passes over the row in L2 took 71 us of the 0.18 ms loss.)
+    constexpr int TOPK_NV = 40;
+    const bool inreg = g.A <= 256 * TOPK_NV;
+    float vals[TOPK_NV];
+    if (inreg) {
+#pragma unroll
+        for (int i = 0; i < TOPK_NV; ++i) {
+            const int a = threadIdx.x + 256 * i;
+            vals[i] = a < g.A ? row[a] : -__builtin_inff();  // (never beats the initial candidate of value -1)
+        }
+    }
     for (int r = 0; r < topk && r < g.A; ++r) {
         Best mine{-1.0f, 0x7fffffff};
-        for (int a = threadIdx.x; a < g.A; a += 256) {
-            const float v = row[a];
-            // candidates: strictly after the previous pick in (value desc, index asc) order
-            const bool cand = v < prev.v || (v == prev.v && a > prev.i);
-            if (cand) mine = better(mine, Best{v, a});
+        if (inreg) {
+#pragma unroll
+            for (int i = 0; i < TOPK_NV; ++i) {
+                const int a = threadIdx.x + 256 * i;
+                const float v = vals[i];
+                const bool cand = v < prev.v || (v == prev.v && a > prev.i);
+                if (cand) mine = better(mine, Best{v, a});
+            }
+        } else {
+            for (int a = threadIdx.x; a < g.A; a += 256) {
+                const float v = row[a];
+                // candidates: strictly after the previous pick in (value desc, index asc) order
+                const bool cand = v < prev.v || (v == prev.v && a > prev.i);
+                if (cand) mine = better(mine, Best{v, a});
+            }
         }
         const Best win = block_best(mine, sh);
         if (win.i == 0x7fffffff) break;
