@@ -1,6 +1,9 @@
 // Optional per-launch timing of the MFMA GEMM kernels with HIP events recorded on the launch stream.
 // Used by bench.py to measure the dominant kernel's achieved FLOP/s live over the timed region.
 // Off by default: when disabled the launch path does not touch this file's state beyond one flag read.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <vector>
 
 #include "common.h"
@@ -68,15 +71,19 @@ extern "C" int ymi_profile_end_ex(double* ms_by_family, double* flop_by_family, 
         ymi_set_error("profile_end: device synchronize failed");
         return YMI_ELAUNCH;
     }
+    // development aid: YMI_PROF_DUMP=<file> appends one line per recorded launch (family, measured us, its own bound in us, GFLOP, MB)
+    FILE* dump = getenv("YMI_PROF_DUMP") ? fopen(getenv("YMI_PROF_DUMP"), "a") : nullptr;
     for (const Rec& r : g_recs) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) continue;
+        if (dump) fprintf(dump, "%d %.2f %.2f %.3f %.2f\n", r.family, ms * 1e3, r.bound_ms * 1e3, r.flop * 1e-9, r.bytes * 1e-6);
         ms_by_family[r.family] += ms;
         flop_by_family[r.family] += r.flop;
         launches_by_family[r.family] += 1;
         if (bytes_by_family) bytes_by_family[r.family] += r.bytes;
         if (bound_ms_by_family) bound_ms_by_family[r.family] += r.bound_ms;
     }
+    if (dump) fclose(dump);
     g_recs.clear();
     g_next = 0;
     return YMI_OK;
