@@ -394,38 +394,55 @@ __global__ void wgrad_reduce_kernel(const void* __restrict__ slab, int splits, i
 // element in a fixed order (deterministic) and scatters into OIHW.  By the end of the backward pass the slabs have left the
 // caches: this kernel streams them from HBM, 4 elements per lane and load, four split chains in flight per lane.
 template <bool BF> __device__ __forceinline__ void reduce_batch_body(const ymi_wgrad_pending& e, f32x4* red) {
-    const int SL = e.lanes, OUTS = 256 / SL;              // OUTS groups of 4 consecutive elements per workgroup
+    // a lane owns EPT consecutive elements: 8 (one 16-byte load per split) of a bfloat16 slab, 4 of a float32 slab
+    constexpr int EPT = BF ? 8 : 4, Q = EPT / 4;
+    const int SL = e.lanes, OUTS = 256 / SL;              // OUTS groups of EPT consecutive elements per workgroup
     const int ol = threadIdx.x % OUTS, lane = threadIdx.x / OUTS;
-    const int64_t el = ((int64_t)((int)blockIdx.x - e.first_block) * OUTS + ol) * 4;  // first element of this lane's group
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    const int64_t el = ((int64_t)((int)blockIdx.x - e.first_block) * OUTS + ol) * EPT;  // first element of this lane's group
+    f32x4 s0[Q], s1[Q], s2[Q], s3[Q];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) s0[q] = s1[q] = s2[q] = s3[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto add_split = [&](f32x4 (&acc)[Q], int k) {
+        const int64_t off = el + (int64_t)k * e.elems;
+        if constexpr (BF) {
+            const bf16x8 v = *reinterpret_cast<const bf16x8*>(reinterpret_cast<const bf16_t*>(e.slab) + off);
+            acc[0] += f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+            acc[1] += f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+        } else {
+            acc[0] += *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(e.slab) + off);
+        }
+    };
     if (el < e.elems) {  // elems is a multiple of 8
         int k = lane;
-        for (; k + 3 * SL < e.splits; k += 4 * SL) {
-            const f32x4 a = slab4_at<BF>(e.slab, el + (int64_t)k * e.elems);
-            const f32x4 b = slab4_at<BF>(e.slab, el + (int64_t)(k + SL) * e.elems);
-            const f32x4 c = slab4_at<BF>(e.slab, el + (int64_t)(k + 2 * SL) * e.elems);
-            const f32x4 d = slab4_at<BF>(e.slab, el + (int64_t)(k + 3 * SL) * e.elems);
-            s0 += a; s1 += b; s2 += c; s3 += d;
+        for (; k + 3 * SL < e.splits; k += 4 * SL) {  // four split chains in flight per lane
+            add_split(s0, k);
+            add_split(s1, k + SL);
+            add_split(s2, k + 2 * SL);
+            add_split(s3, k + 3 * SL);
         }
-        for (; k < e.splits; k += SL) s0 += slab4_at<BF>(e.slab, el + (int64_t)k * e.elems);
+        for (; k < e.splits; k += SL) add_split(s0, k);
     }
-    red[lane * OUTS + ol] = (s0 + s1) + (s2 + s3);
+#pragma unroll
+    for (int q = 0; q < Q; ++q) red[(q * SL + lane) * OUTS + ol] = (s0[q] + s1[q]) + (s2[q] + s3[q]);
     __syncthreads();
     if (lane == 0 && el < e.elems) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < SL; ++q) s += red[q * OUTS + ol];
-        const uint32_t eu = (uint32_t)el;  // < 2^31; the 4 elements share (co, tap): ng and cin are multiples of 4
-        const int co = (int)(eu / (uint32_t)e.ng), col = (int)(eu - (uint32_t)co * (uint32_t)e.ng);
-        const int tap = (int)((uint32_t)col / (uint32_t)e.cin), ci = col - tap * e.cin;
-        if (co < e.cout_real) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (ci + r < e.cin_real) e.dw[((int64_t)co * e.cin_real + ci + r) * e.ntaps + tap] = s[r];
+        for (int q = 0; q < Q; ++q) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < SL; ++c) s += red[(q * SL + c) * OUTS + ol];
+            const uint32_t eu = (uint32_t)el + 4u * q;  // < 2^31; 4 elements share (co, tap): ng and cin are multiples of 4
+            const int co = (int)(eu / (uint32_t)e.ng), col = (int)(eu - (uint32_t)co * (uint32_t)e.ng);
+            const int tap = (int)((uint32_t)col / (uint32_t)e.cin), ci = col - tap * e.cin;
+            if (co < e.cout_real) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (ci + r < e.cin_real) e.dw[((int64_t)co * e.cin_real + ci + r) * e.ntaps + tap] = s[r];
+            }
         }
     }
 }
 __global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ymi_wgrad_pending* __restrict__ tab, int n) {
-    __shared__ f32x4 red[256];
+    __shared__ f32x4 red[512];
     int lo = 0, hi = n - 1;  // last entry whose first_block <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -592,8 +609,9 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     const int64_t elems = (int64_t)a.CoutP * a.NG;
     if (pending) {  // the slab sum is left to ymi_wgrad_reduce_batch (one launch for every layer of the backward pass)
         const int lanes = p.splits > 128 ? 32 : p.splits > 32 ? 16 : p.splits > 8 ? 8 : 4;
+        const int ept = a.slab_bf16 ? 8 : 4;  // elements per lane of the batched sum (one 16-byte load per split)
         *pending = ymi_wgrad_pending{a.slab, dw_oihw, elems, p.splits, a.NG, a.Cin, (int32_t)cout_real, (int32_t)cin_real, (int32_t)(kh * kw), lanes, 0,
-                                     (int32_t)((elems / 4 + 256 / lanes - 1) / (256 / lanes)), a.slab_bf16};
+                                     (int32_t)((elems / ept + 256 / lanes - 1) / (256 / lanes)), a.slab_bf16};
     } else {
         const int64_t total = cout_real * kh * kw * cin_real;
         int64_t gb = (total + 255) / 256;

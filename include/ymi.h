@@ -171,7 +171,7 @@ typedef struct ymi_wgrad_pending {
     int32_t splits, ng, cin, cout_real, cin_real, ntaps;
     int32_t lanes;       /* interleaved split chains per output element (4, 8, 16 or 32) */
     int32_t first_block; /* set by ymi_wgrad_reduce_batch */
-    int32_t blocks;      /* workgroups this record needs: ceil(elems / 4 / (256 / lanes)) */
+    int32_t blocks;      /* workgroups this record needs: ceil(elems / e / (256 / lanes)), e = 8 elements per lane for bfloat16 slabs, 4 for float32 */
     int32_t slab_bf16;   /* 1: the slabs hold bfloat16 (the bf16 path), 0: float32 (parity mode) */
 } ymi_wgrad_pending;
 int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
