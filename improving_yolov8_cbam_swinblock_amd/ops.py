@@ -159,8 +159,9 @@ class WeightArena:
             w = sp["weight"]
             descs[n] = _PackDesc(w.data_ptr(), base + offf * es if nf else None, base + offd * es if nd else None, sp["o"], sp["i"], sp["k"],
                                  sp["k"], sp["ipad"] or 0, sp["opad"] or 0, sp["stride"], 0)
-            pairs = max(sp["o"] * sp["ipad"] if nf else 0, sp["i"] * sp["opad"] if nd else 0)  # one thread per (channel, padded channel) pair
-            starts.append(starts[-1] + (pairs + 255) // 256)
+            # workgroups: one per 32 x 32 tile of (output, input) channels, padded extents included (include/ymi.h)
+            wgs = ((max(sp["o"], sp["opad"] if nd else 0) + 31) // 32) * ((max(sp["i"], sp["ipad"] if nf else 0) + 31) // 32)
+            starts.append(starts[-1] + wgs)
             self.views[key] = (self.arena[offf : offf + nf] if nf else None, self.arena[offd : offd + nd] if nd else None, sp["ipad"], sp["opad"], sp["stride"])
         raw = bytes(descs)
         self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)

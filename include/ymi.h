@@ -92,8 +92,9 @@ int ymi_pack_conv_weight_dgrad(const float* w_oihw, int64_t o, int64_t i, int64_
 int ymi_pack_conv_weight_dgrad_ex(const float* w_oihw, int64_t o_real, int64_t o_pad, int64_t i, int64_t kh, int64_t kw, int64_t stride, int32_t dtype, void* dst, void* stream);
 int64_t ymi_conv_dgrad_pack_elems(int64_t o, int64_t i, int64_t kh, int64_t kw, int64_t stride);
 /* All weights of a model in ONE launch.  descs_device: array of ymi_pack_desc in device memory; block_start_device:
- * int32[count+1] prefix sums of ceil(max(o * ipad if dst_fwd, i * opad if dst_dgrad) / 256) per tensor (one thread per
- * (channel, padded channel) pair, looping over the taps); either destination may be NULL.
+ * int32[count+1] prefix sums of the workgroups per tensor = ceil(max(o, opad if dst_dgrad) / 32) * ceil(max(i, ipad if dst_fwd) / 32)
+ * (a workgroup reads a 32 x 32 channel tile of the source once and writes both operands from LDS); either destination may be
+ * NULL; kh * kw <= 9.
  * Same layouts as ymi_pack_conv_weight_fwd / _dgrad_ex (nn.Linear weights: kh = kw = 1). */
 typedef struct ymi_pack_desc {
     const float* src;

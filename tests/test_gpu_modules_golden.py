@@ -401,7 +401,9 @@ def test_weight_arena_pack_equals_per_call_pack():
     from improving_yolov8_cbam_swinblock_amd import ops
 
     torch.manual_seed(3)
-    cases = [(24, 13, 3, 2, 16, 24), (64, 64, 3, 1, 64, 64), (40, 32, 1, 1, 32, 40), (7, 8, 3, 2, 8, 8)]  # (o, i, k, stride, ipad, opad)
+    # (o, i, k, stride, ipad, opad); the data-gradient operand is transposed through LDS in 32 x 32 channel tiles: partial tiles on both axes
+    cases = [(24, 13, 3, 2, 16, 24), (64, 64, 3, 1, 64, 64), (40, 32, 1, 1, 32, 40), (7, 8, 3, 2, 8, 8), (96, 40, 3, 1, 40, 96),
+             (130, 70, 1, 1, 72, 136), (256, 128, 3, 2, 128, 256), (1, 64, 1, 1, 64, 8)]
     for dt in (torch.bfloat16, torch.float32):
         arena = ops.WeightArena()
         ops.set_weight_arena(arena)
