@@ -98,7 +98,7 @@ _SIGNATURES = {
     "ymi_detect_loss_sizes": (_c_i32, [_c_i64, _c_i64, _c_i64, ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_size_t)]),
     "ymi_detect_loss_fwd": (_c_i32, [_c_i32, _TP, _TP, ctypes.POINTER(ctypes.c_float), _vp, _c_i64, _c_i32, ctypes.c_float, ctypes.c_float,
                                      _vp, _vp, _vp, _sz, _vp, _sz, _vp]),
-    "ymi_detect_loss_bwd": (_c_i32, [_c_i32, _TP, _TP, ctypes.POINTER(ctypes.c_float), _vp, _sz, _vp, _TP, _TP, _vp]),
+    "ymi_detect_loss_bwd": (_c_i32, [_c_i32, _TP, _TP, ctypes.POINTER(ctypes.c_float), _vp, _sz, _vp, _vp, _TP, _TP, _vp]),
     "ymi_detect_decode": (_c_i32, [_c_i32, _TP, _TP, ctypes.POINTER(ctypes.c_float), _vp, _vp]),
     "ymi_opt_chunk_elems": (_c_i64, []),
     "ymi_opt_grad_norm": (_c_i32, [_vp, _vp, _c_i32, _c_i32, _c_i64, ctypes.POINTER(_vp), _vp, _vp, _c_i64, _c_i64, _vp, _c_i32, _vp]),

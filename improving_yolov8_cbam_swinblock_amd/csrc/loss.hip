@@ -24,6 +24,7 @@ struct LossGeom {
     int H[LOSS_MAXL], W[LOSS_MAXL], off[LOSS_MAXL + 1];
     float stride[LOSS_MAXL];
     int nl, B, A, G, nc;
+    int dcw;  // backward: channels of the class-gradient maps (>= nc; the ones beyond nc are written as zeros: padded gradient buffers)
 };
 
 struct Anchor {
@@ -461,7 +462,7 @@ __global__ __launch_bounds__(256) void finalize_kernel(LossGeom g, const float* 
 template <typename T, bool GRAD>
 __global__ __launch_bounds__(256) void loss_kernel(LossGeom g, const float* __restrict__ tgt, const float* __restrict__ wgt,
                                                    const int* __restrict__ lab, const float* __restrict__ scal, const float* __restrict__ gout,
-                                                   float* __restrict__ part) {
+                                                   const float* __restrict__ gscale, float* __restrict__ part) {
     __shared__ float sh[3][4];
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t quad = t >> 2;
@@ -489,9 +490,9 @@ __global__ __launch_bounds__(256) void loss_kernel(LossGeom g, const float* __re
     float inv_t = 0.f, g_box = 0.f, g_cls = 0.f, g_dfl = 0.f;
     if (GRAD) {
         inv_t = 1.0f / fmaxf(scal[0], 1.0f);
-        g_box = gout[0] * inv_t;
-        g_cls = gout[1] * inv_t;
-        g_dfl = gout[2] * inv_t;
+        g_box = gout[0] * (gscale ? gscale[0] : 1.0f) * inv_t;
+        g_cls = gout[1] * (gscale ? gscale[1] : 1.0f) * inv_t;
+        g_dfl = gout[2] * (gscale ? gscale[2] : 1.0f) * inv_t;
     }
     if (lb >= 0) {  // foreground anchor
         if (!GRAD) {
@@ -535,6 +536,10 @@ __global__ __launch_bounds__(256) void loss_kernel(LossGeom g, const float* __re
                 T* dp = reinterpret_cast<T*>(pick(g.dcls, an.l)) + an.pix * pick(g.lddc, an.l);
                 dp[c] = from_f32<T>((sigmoidf_(xv) - tv) * g_cls);
             }
+        }
+        if (GRAD) {  // zero padding channels of a padded gradient buffer (the consumer's weight-gradient GEMM reads them)
+            T* dp = reinterpret_cast<T*>(pick(g.dcls, an.l)) + an.pix * pick(g.lddc, an.l);
+            for (int c = g.nc + side; c < g.dcw; c += 4) dp[c] = from_f32<T>(0.f);
         }
     }
     if (!GRAD) {
@@ -716,15 +721,15 @@ extern "C" int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const
     hipLaunchKernelGGL(assign_kernel, agrid, dim3(256), 0, s, g, ov, mpos, gidx);
     hipLaunchKernelGGL(posmax_kernel, dim3((unsigned)BG), dim3(256), 0, s, g, ov, al, gidx, pa, po);
     hipLaunchKernelGGL(finalize_kernel, agrid, dim3(256), 0, s, g, targets, al, gidx, pa, po, st.tgt, st.wgt, st.lab, tss_part);
-    if (bf) hipLaunchKernelGGL((loss_kernel<bf16_t, false>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, nullptr, part);
-    else hipLaunchKernelGGL((loss_kernel<float, false>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, nullptr, part);
+    if (bf) hipLaunchKernelGGL((loss_kernel<bf16_t, false>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, nullptr, nullptr, part);
+    else hipLaunchKernelGGL((loss_kernel<float, false>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, nullptr, nullptr, part);
     hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(256), 0, s, tss_part, (int)(agrid.x * agrid.y), part, (int)qblocks, st.scal, loss_out, out_scale);
     YMI_CHECK_LAUNCH("detect_loss_fwd");
     return YMI_OK;
 }
 
 extern "C" int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const void* state,
-                                   size_t state_bytes, const float* grad_loss, const ymi_tensor* dbox_maps, const ymi_tensor* dcls_maps,
+                                   size_t state_bytes, const float* grad_loss, const float* grad_scale, const ymi_tensor* dbox_maps, const ymi_tensor* dcls_maps,
                                    void* stream) {
     LossGeom g;
     int rc = fill_geom(g, nl, box_maps, cls_maps, strides, 1, "detect_loss_bwd");
@@ -735,22 +740,24 @@ extern "C" int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const
     StateView st = carve_state(const_cast<void*>(state), BA, &sb);
     YMI_CHECK_ARG(state_bytes >= sb, "detect_loss_bwd: state too small");
     for (int l = 0; l < nl; ++l) {
-        YMI_CHECK_ARG(ymi_tensor_ok(&dbox_maps[l]) && ymi_tensor_ok(&dcls_maps[l]) && ymi_same_shape(&dbox_maps[l], &box_maps[l]) &&
-                          ymi_same_shape(&dcls_maps[l], &cls_maps[l]) && dbox_maps[l].dtype == box_maps[l].dtype && dcls_maps[l].dtype == cls_maps[l].dtype,
+        const ymi_tensor &dc = dcls_maps[l], &cm = cls_maps[l];
+        YMI_CHECK_ARG(ymi_tensor_ok(&dbox_maps[l]) && ymi_tensor_ok(&dc) && ymi_same_shape(&dbox_maps[l], &box_maps[l]) && dc.n == cm.n && dc.h == cm.h &&
+                          dc.w == cm.w && dc.c >= cm.c && dc.c == dcls_maps[0].c && dbox_maps[l].dtype == box_maps[l].dtype && dc.dtype == cm.dtype,
                       "detect_loss_bwd: gradient map %d", l);
         const int es = (int)ymi_esize(dbox_maps[l].dtype);
         YMI_CHECK_ARG(((uintptr_t)dbox_maps[l].data % 16) == 0 && (dbox_maps[l].ld * es) % 16 == 0, "detect_loss_bwd: gradient map alignment");
         g.dbox[l] = dbox_maps[l].data;
         g.dcls[l] = dcls_maps[l].data;
+        g.dcw = (int)dcls_maps[l].c;
         g.lddb[l] = dbox_maps[l].ld;
         g.lddc[l] = dcls_maps[l].ld;
     }
     const unsigned qblocks = (unsigned)((BA * 4 + 255) / 256);
     hipStream_t s = (hipStream_t)stream;
     if (box_maps[0].dtype == YMI_BF16)
-        hipLaunchKernelGGL((loss_kernel<bf16_t, true>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, grad_loss, nullptr);
+        hipLaunchKernelGGL((loss_kernel<bf16_t, true>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, grad_loss, grad_scale, nullptr);
     else
-        hipLaunchKernelGGL((loss_kernel<float, true>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, grad_loss, nullptr);
+        hipLaunchKernelGGL((loss_kernel<float, true>), dim3(qblocks), dim3(256), 0, s, g, st.tgt, st.wgt, st.lab, st.scal, grad_loss, grad_scale, nullptr);
     YMI_CHECK_LAUNCH("detect_loss_bwd");
     return YMI_OK;
 }

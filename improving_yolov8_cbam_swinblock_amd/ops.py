@@ -782,20 +782,23 @@ class _ChanSlice(torch.autograd.Function):
 _zero_padded = {}  # data_ptr -> padded buffer whose [:, :c] view padded_grad_like handed out (dropped when _ChanSlice.backward takes it)
 
 
-def padded_grad_like(t):
-    """a gradient buffer for tensor t: if t is the [:, :c] view of a channel-padded NHWC tensor (pixel stride ld > c), a zeroed
-    buffer of the PADDED shape whose [:, :c] view is returned (see _ChanSlice.backward); else an empty tensor like t."""
+def padded_grad_like(t, zero=True):
+    """a gradient buffer for tensor t: if t is the [:, :c] view of a channel-padded NHWC tensor (pixel stride ld > c), a buffer of the
+    PADDED shape (see _ChanSlice.backward, which hands it through); else an empty tensor like t.  -> (tensor for the kernel, [:, :c] view
+    to return to autograd).  zero=False: the kernel that fills it writes zeros into the padding channels itself."""
     if t.dim() == 4 and is_nhwc(t):
         ld = as_ymi(t).ld
         n, c, h, w = t.shape
         if ld != c and ld % chunk_elems(t.dtype) == 0 and ld - c < chunk_elems(t.dtype):
             base = empty_nhwc(n, ld, h, w, t.dtype, t.device)
-            base.zero_()
+            if zero:
+                base.zero_()
             if len(_zero_padded) > 64:  # (gradients that never reached a _ChanSlice: do not keep their buffers alive)
                 _zero_padded.clear()
             _zero_padded[base.data_ptr()] = base
-            return base[:, :c]
-    return torch.empty_like(t)
+            return base, base[:, :c]
+    e = torch.empty_like(t)
+    return e, e
 
 
 def linear(x, weight, bias=None, residual=None):
@@ -1301,6 +1304,7 @@ class _DetectLoss(torch.autograd.Function):
         ctx.strides = st
         loss, items = out[:3], out[3:]
         ctx.mark_non_differentiable(items)
+        ctx.set_materialize_grads(False)  # (no zero tensor for `items`: it was a fill launch per step)
         return loss, items
 
     @staticmethod
@@ -1308,12 +1312,18 @@ class _DetectLoss(torch.autograd.Function):
         state, scale6, *maps = ctx.saved_tensors
         nl = len(maps) // 2
         box, cls = maps[:nl], maps[nl:]
-        gl = gl.to(torch.float32) * scale6[:3]  # the kernel differentiates the unscaled sums
+        if gl is None:
+            return (None,) * (6 + len(maps))
+        if gl.dtype != torch.float32 or not gl.is_contiguous():
+            gl = gl.to(torch.float32).contiguous()
         dbox = [torch.empty_like(t) for t in box]
-        dcls = [padded_grad_like(t) for t in cls]
-        check(
-            L().ymi_detect_loss_bwd(nl, _map_array(box), _map_array(cls), ctx.strides, ptr(state), state.numel(), ptr(gl), _map_array(dbox),
-                                    _map_array(dcls), stream_ptr()),
+        pairs = [padded_grad_like(t, zero=False) for t in cls]
+        if len({p[0].shape[1] for p in pairs}) != 1:  # (levels padded differently: the kernel takes one width) zeroed buffers, class channels only
+            pairs = [(v, v) for v in (padded_grad_like(t)[1] for t in cls)]
+        dcls_k, dcls = [p[0] for p in pairs], [p[1] for p in pairs]
+        check(  # the kernel differentiates the unscaled sums: the forward's scale rides along as grad_scale; padding channels are zeroed there
+            L().ymi_detect_loss_bwd(nl, _map_array(box), _map_array(cls), ctx.strides, ptr(state), state.numel(), ptr(gl), ptr(scale6), _map_array(dbox),
+                                    _map_array(dcls_k), stream_ptr()),
             "detect_loss_bwd",
         )
         return (None, None, None, None, None, None, *dbox, *dcls)

@@ -268,10 +268,13 @@ int ymi_detect_loss_sizes(int64_t batch, int64_t anchors, int64_t max_boxes, siz
 int ymi_detect_loss_fwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const float* targets,
                         int64_t max_boxes, int32_t topk, float alpha, float beta, const float* out_scale, float* loss_out, void* state,
                         size_t state_bytes, void* workspace, size_t workspace_bytes, void* stream);
-/* gradients of sum_k grad_loss[k] * raw[k] with respect to the maps (grad_loss: device [3]).  dcls_maps may be channel slices of
- * wider buffers (ld > c): only the nc class channels are written. */
+/* gradients of sum_k grad_loss[k] * grad_scale[k] * raw[k] with respect to the maps (grad_loss: device [3]; grad_scale: device [3]
+ * or NULL = 1: the out_scale[0..2] the forward multiplied its differentiable result by).  dcls_maps may be channel slices of
+ * wider buffers (ld > c); they may also have MORE channels than the class maps (the same count on every level): the extra
+ * channels are written as zeros (channel-padded gradient buffers need no separate fill). */
 int ymi_detect_loss_bwd(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* cls_maps, const float* strides, const void* state,
-                        size_t state_bytes, const float* grad_loss, const ymi_tensor* dbox_maps, const ymi_tensor* dcls_maps, void* stream);
+                        size_t state_bytes, const float* grad_loss, const float* grad_scale, const ymi_tensor* dbox_maps,
+                        const ymi_tensor* dcls_maps, void* stream);
 
 /* Detect._inference (nn/modules/head.py:103-142, non-export branch; DFL nn/modules/block.py:58-77; make_anchors /
  * dist2bbox utils/tal.py:364-388): per level l a box map [B,H,W,64] and a class map [B,H,W,nc] (NHWC, channel slices of
