@@ -1109,8 +1109,12 @@ static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t 
             finish_args(a, dx, nullptr);
             classes[nlaunch++] = a;
         } else if (ho > 0 && wo > 0) {
-            ymi_set_error("conv2d_bwd_data: parity class without taps (k=1 stride=2 is not supported)");
-            return YMI_EINVAL;
+            // a parity class no tap reaches (k = 1, stride 2: three of the four classes): its pixels receive no gradient.  They are left
+            // as the caller prepared them - the contract of this case: dx pre-filled with zeros, addends applied by the caller
+            if (add1 || add2) {
+                ymi_set_error("conv2d_bwd_data: epilogue addends are not available when a parity class has no taps (k=1 stride=2): add them separately");
+                return YMI_EINVAL;
+            }
         }
         woff += (int64_t)nt * dy->c * cin;
     }

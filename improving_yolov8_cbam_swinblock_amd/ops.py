@@ -514,7 +514,10 @@ def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None):
         dx.zero_()
         dxv = dx[:, :cin]
     adds = _prep_adds(adds, dtype, True)
-    fused = adds[:2] if cp == cin else []
+    sparse = k == 1 and stride > 1  # pixels between the strides receive no gradient: the kernel leaves them as prepared here (zeros)
+    if sparse and cp == cin:
+        dx.zero_()  # (_dgrad_joined never passes an in-place `out` in this case)
+    fused = adds[:2] if (cp == cin and not sparse) else []
     a1 = _byref(as_ymi(fused[0])) if len(fused) > 0 else None
     a2 = _byref(as_ymi(fused[1])) if len(fused) > 1 else None
     check(L().ymi_conv2d_bwd_data_add(_byref(ty), ptr(wd), cin, k, k, stride, a1, a2, _byref(as_ymi(dxv)), stream_ptr()), "conv2d_bwd_data")
@@ -529,7 +532,7 @@ def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype):
     out = None
     if adds is not None and join is not None and join.out is not None:
         out, join.out = join.out, None
-        if len(adds) < 2 and _dense_ok(out, dtype) and tuple(out.shape) == tuple(in_shape):
+        if len(adds) < 2 and _dense_ok(out, dtype) and tuple(out.shape) == tuple(in_shape) and not (k == 1 and stride > 1):
             adds = list(adds) + [out]  # the contribution already in the buffer rides as an addend; the total replaces it
         else:
             out = None  # (left for _C2fSplit's own add)

@@ -152,7 +152,8 @@ int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_
 /* the same with up to two addends in the epilogue: dx = dgrad(dy) + add1 (+ add2).  An addend may BE dx (in-place
  * accumulation).  This is how the gradient sums of tensors with several consumers (Bottleneck shortcut block.py:488, the
  * two Detect branches head.py:72, neck skip connections yolov8.yaml:760-773, SwinBlock residuals swin_block.py:52-53) are
- * formed without separate add kernels. */
+ * formed without separate add kernels.  kh = kw = 1 with stride 2: only the pixels on the stride grid receive a gradient; the others
+ * are left as the caller prepared them (zeros) and addends must be NULL (EINVAL otherwise). */
 int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
                             const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream);
 /* dw (OIHW f32 [cout_real][cin_real][kh][kw], overwritten) = sum over pixels dy (x) x ; optional
