@@ -173,3 +173,59 @@ def test_composite_modules_random_shapes_vs_oracle():
         if max(errs) > worst[0]:
             worst = (max(errs), case)
     print(f"\n[fuzz modules f32, {max(CASES // 2, 8)} cases] worst {worst[0]:.2e} ({worst[1]})")
+
+
+# (forward, gradient) relative-L2 bounds per module kind.  Soak of 1000 cases (round 3): worst C2f 5.0e-3 / 2.4e-2 (up to three Bottlenecks: a
+# chain of eight stored tensors, roundings that fall differently cascade - tools/c2f_matched_diag.py), Bottleneck 6.9e-4 / 2.2e-3, SwinBlock
+# 3.2e-4 / 2.6e-3, CBAM 1.1e-4 / 3.1e-3, SPPF 7.2e-4 / 3.0e-2 (the gradient is routed by arg-max over bf16-rounded values).  A wrong row,
+# channel or tap is O(1).
+BF16_MODULE_BOUNDS = {"C2f": (8e-3, 4e-2), "Bottleneck": (2e-3, 6e-3), "SPPF": (2e-3, 5e-2), "CBAM": (1e-3, 1e-2), "SwinBlock": (1e-3, 8e-3)}
+
+
+def test_composite_modules_random_shapes_bf16_vs_matched_oracle():
+    """the same modules in bf16 against the quantisation-matched oracle, per-kind bounds (BF16_MODULE_BOUNDS above)."""
+    import oracle.modules as OM
+    from oracle import quant
+    from improving_yolov8_cbam_swinblock_amd.nn import modules as PM
+
+    worst = {}
+    for idx, (kind, args, shape) in enumerate(_module_cases(78, max(CASES // 2, 8))):
+        torch.manual_seed(idx)
+        o = getattr(OM, kind)(*args)
+        if kind == "CBAM" and o.ca.shared_MLP is None:
+            o.ca.create_mlp(shape[1])
+        for bn in o.modules():
+            if isinstance(bn, torch.nn.BatchNorm2d):
+                bn.eps, bn.momentum = 1e-3, 0.03
+                bn.weight.data.uniform_(0.5, 1.5)
+                bn.bias.data.normal_(0, 0.3)
+        quant.round_weights_(o)
+        m = getattr(PM, kind)(*args)
+        if kind == "CBAM" and m.ca.shared_MLP is None:
+            m.ca.create_mlp(shape[1])
+        for bn in m.modules():
+            if isinstance(bn, torch.nn.BatchNorm2d):
+                bn.eps, bn.momentum = 1e-3, 0.03
+        m.load_state_dict(o.state_dict())
+        m = m.to(dev()).train()
+        o.train()
+        x = q(torch.randn(*shape))
+        xo = x.clone().requires_grad_(True)
+        with quant.storage(torch.bfloat16):
+            yo = o(xo)
+            gy = q(torch.randn_like(yo))
+            po = [p for p in o.parameters() if p.requires_grad]
+            go = torch.autograd.grad(yo, [xo] + po, gy)
+        xg = x.to(dev()).requires_grad_(True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            yg = m(xg)
+        pg = [p for p in m.parameters() if p.requires_grad]
+        gg = torch.autograd.grad(yg, [xg] + pg, gy.to(dev()).to(yg.dtype))
+        case = f"{kind}{args} {shape}"
+        ef = rel(yg, yo)
+        eg = max(rel(a, q(b) if i == 0 else b) for i, (a, b) in enumerate(zip(gg, go)))
+        fb, gb = BF16_MODULE_BOUNDS[kind]
+        assert ef <= fb and eg <= gb, (case, ef, eg)
+        w = worst.setdefault(kind, [0.0, 0.0])
+        w[0], w[1] = max(w[0], ef), max(w[1], eg)
+    print(f"\n[fuzz modules bf16, {max(CASES // 2, 8)} cases] worst (forward, gradient): " + "; ".join(f"{k} {v[0]:.1e} {v[1]:.1e}" for k, v in worst.items()))
