@@ -5,7 +5,8 @@
 #   kernel_categories.txt    per-family ms/step of the same
 #   bench_under_rocprof.json the bench line printed by that profiled run
 #   pmc_traffic.json         HBM bytes per launch of the GEMM families: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE)
-# usage: tools/round_profiles.sh TAG
+#   bench_cfg5.json          (second argument `cfg5`) config 5: yolov8m-cbam-swin384 at bs 16, 1280x1280
+# usage: tools/round_profiles.sh TAG [cfg5]
 set -e
 tag=$1
 root=${GRAFT_REPO_ROOT:-/root/repo}
@@ -23,6 +24,13 @@ echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/pmc_write -o p -- python3 $root/bench.py --no-cpu-baseline --no-forward --sustained 0 --steps 3 --warmup 1 > /dev/null 2> $out/pmc_write.err
 echo "write pass done"
 python3 $root/tools/pmc_traffic.py $out/pmc_fetch $out/pmc_write $out/pmc_traffic.json > /dev/null
+# the default line once more, now that the PMC passes of THIS kernel revision exist (bench.py reports `traffic` only from a matching file)
+cp $out/pmc_traffic.json $root/profiles/r03_pmc_traffic.json
+python3 $root/bench.py > $out/bench.json 2> $out/bench.err
+if [ "$2" = "cfg5" ]; then
+  python3 $root/bench.py --model yolov8m-cbam-swin384.yaml --batch 16 --imgsz 1280 --no-cpu-baseline --steps 10 --warmup 3 --sustained 20 > $out/bench_cfg5.json 2> $out/bench_cfg5.err
+  echo "cfg5 done"
+fi
 rm -rf $out/pmc_fetch $out/pmc_write $out/trace/*kernel_trace.csv $out/trace/*/*kernel_trace.csv 2>/dev/null || true
 cat $out/kernel_categories.txt | head -14
 cat $out/pmc_traffic.json
