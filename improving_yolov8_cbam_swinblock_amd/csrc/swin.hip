@@ -608,7 +608,29 @@ __device__ __forceinline__ bf16x8 attn_tr_frag(const char* img, int rowb, int k0
 // the first LDS store (these kernels are latency-bound: a load->store round per matrix costs more than the arithmetic)
 template <int NM>
 __device__ __forceinline__ void attn_stage_rows(const bf16_t* const (&srcs)[NM], const int64_t (&lds_)[NM], char* const (&dsts)[NM], int L, int hd, int hdp) {
-    const int g4 = hdp / 4, items = 64 * g4, rstride = (hdp + 8) * 2;
+    const int rstride = (hdp + 8) * 2;
+    bool wide = (hd & 7) == 0 && (hdp & 7) == 0;  // 16-byte chunks (8 channels): half the load instructions of the 8-byte form
+#pragma unroll
+    for (int mtx = 0; mtx < NM; ++mtx) wide = wide && (lds_[mtx] & 7) == 0 && (((uintptr_t)srcs[mtx]) & 15) == 0;
+    if (wide) {  // (workgroup-uniform)
+        const int g8 = hdp / 8, items = 64 * g8;
+        for (int i = threadIdx.x; i < items; i += 256) {
+            const int r = i / g8, c = (i - r * g8) * 8;
+            const bool ok = r < L && c < hd;
+            bf16x8 v[NM];
+#pragma unroll
+            for (int mtx = 0; mtx < NM; ++mtx) {
+                if (ok) v[mtx] = *reinterpret_cast<const bf16x8*>(srcs[mtx] + (int64_t)r * lds_[mtx] + c);
+                else
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[mtx][e] = (bf16_t)0.f;
+            }
+#pragma unroll
+            for (int mtx = 0; mtx < NM; ++mtx) *reinterpret_cast<bf16x8*>(dsts[mtx] + (size_t)r * rstride + c * 2) = v[mtx];
+        }
+        return;
+    }
+    const int g4 = hdp / 4, items = 64 * g4;
     for (int base = threadIdx.x; base < items; base += 512) {
         bf16x4 v[2][NM];
 #pragma unroll
@@ -650,6 +672,7 @@ __global__ __launch_bounds__(256) void window_attn_fwd_tr_kernel(AttnArgs a) {
     const T* qkv = reinterpret_cast<const T*>(a.qkv.p) + t0 * a.qkv.ld;
     T* out = reinterpret_cast<T*>(const_cast<void*>(a.out.p)) + t0 * a.out.ld;
     const int ndt = (a.hd + 15) / 16;
+    const bool vec4 = (a.hd & 3) == 0 && (a.out.ld & 3) == 0 && (((uintptr_t)a.out.p) & 7) == 0;  // 8-byte stores of 4 channels
     {
         const bf16_t* srcs[3] = {qkv + co, qkv + a.C + co, qkv + 2 * a.C + co};
         const int64_t lds_[3] = {a.qkv.ld, a.qkv.ld, a.qkv.ld};
@@ -703,15 +726,22 @@ __global__ __launch_bounds__(256) void window_attn_fwd_tr_kernel(AttnArgs a) {
         if (dt < ndt) {
             f32x4 o = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
+            // operands swapped (first = V^T fragment: rows d, second = P rows: columns m), so a lane's four values are four CONSECUTIVE
+            // channels of one query: one 8-byte store instead of four 2-byte stores to four rows
             for (int k0 = 0; k0 < 64; k0 += 32) {
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(P + (size_t)(16 * wv + l15) * tstride + (k0 + 8 * l4) * 2);
-                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, attn_tr_frag(Vs, rstride, k0, 16 * dt, lane), o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Vs, rstride, k0, 16 * dt, lane), af, o, 0, 0, 0);
             }
-            const int d = dt * 16 + l15;
+            const int d = dt * 16 + 4 * l4, mq = wv * 16 + l15;
+            if (mq < L) {
+                T* dst = out + (int64_t)mq * a.out.ld + co + d;
+                if (vec4 && d + 3 < a.hd) {
+                    *reinterpret_cast<bf16x4*>(dst) = bf16x4{(T)o[0], (T)o[1], (T)o[2], (T)o[3]};
+                } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int mq = wv * 16 + 4 * l4 + r;
-                if (mq < L && d < a.hd) out[(int64_t)mq * a.out.ld + co + d] = (T)o[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (d + r < a.hd) dst[r] = (T)o[r];
+                }
             }
         }
 }
@@ -736,15 +766,12 @@ __global__ __launch_bounds__(256) void window_attn_bwd_tr_kernel(AttnArgs a) {
     const T* dO = reinterpret_cast<const T*>(a.dout.p) + t0 * a.dout.ld;
     T* dqkv = reinterpret_cast<T*>(const_cast<void*>(a.dqkv.p)) + t0 * a.dqkv.ld;
     const int ndt = (a.hd + 15) / 16;
+    const bool vec4 = (a.hd & 3) == 0 && (a.C & 3) == 0 && (a.dqkv.ld & 3) == 0 && (((uintptr_t)a.dqkv.p) & 7) == 0;  // 8-byte stores of 4 channels
 
-    // the saved log-sum-exp of this lane's four query rows: requested before the operand staging (it was a dependent global round
-    // trip between the first MFMAs and the softmax)
-    float lse4[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = 16 * wv + 4 * l4 + r;
-        lse4[r] = m < L ? a.lse[(t0 + m) * a.heads + head] : 0.f;
-    }
+    // the saved log-sum-exp of this lane's query row: requested before the operand staging (it was a dependent global round trip
+    // between the first MFMAs and the softmax)
+    const int mrow = 16 * wv + l15;  // this lane's query in the transposed tiles below
+    const float lse = mrow < L ? a.lse[(t0 + mrow) * a.heads + head] : 0.f;
     {
         const bf16_t* srcs[4] = {qkv + co, qkv + a.C + co, qkv + 2 * a.C + co, dO + co};
         const int64_t lds_[4] = {a.qkv.ld, a.qkv.ld, a.qkv.ld, a.dout.ld};
@@ -752,42 +779,35 @@ __global__ __launch_bounds__(256) void window_attn_bwd_tr_kernel(AttnArgs a) {
         attn_stage_rows<4>(srcs, lds_, dsts, L, a.hd, hdp);
     }
     __syncthreads();
-    // this wave owns queries 16*wv..+15: S = Q K^T and dP = dO V^T against the four key tiles
+    // TRANSPOSED tiles, as in the forward: S^T = K Q^T and dP^T = V dO^T, so a lane holds keys j = 16 t + 4 l4 + r (r = 0..3) of ONE
+    // query m = 16 wv + l15: one log-sum-exp per lane, the row sum delta needs two shuffles instead of sixteen, and P / dS go to LDS
+    // as 8-byte stores of four consecutive keys instead of 2-byte stores
     f32x4 s[4], dp[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         s[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         dp[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        AT<T>::mma(Qs, rstride, wv * 16, Ks, rstride, t * 16, hdp, lane, s[t]);
-        AT<T>::mma(Os, rstride, wv * 16, Vs, rstride, t * 16, hdp, lane, dp[t]);
+        AT<T>::mma(Ks, rstride, t * 16, Qs, rstride, wv * 16, hdp, lane, s[t]);
+        AT<T>::mma(Vs, rstride, t * 16, Os, rstride, wv * 16, hdp, lane, dp[t]);
     }
-    // lane holds queries m = 16*wv + 4*l4 + r, keys j = 16*t + l15
-    float pr[4][4], delta[4] = {0.f, 0.f, 0.f, 0.f};
+    float pr[4][4], delta = 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int m = 16 * wv + 4 * l4 + r;
-        const float lse = lse4[r];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const bool ok = (16 * t + l15 < L) && (m < L);
-            pr[t][r] = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
-            delta[r] += pr[t][r] * dp[t][r];  // sum_j P dP = dO . O   (row sum: finished by the 16-lane reduction below)
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) delta[r] += __shfl_xor(delta[r], o, 64);
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int j = 16 * t + l15;
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int m = 16 * wv + 4 * l4 + r;
-            const float ds = pr[t][r] * (dp[t][r] - delta[r]) * a.scale;
-            reinterpret_cast<T*>(Ps + (size_t)m * tstride)[j] = (T)pr[t][r];
-            reinterpret_cast<T*>(Ds + (size_t)m * tstride)[j] = (T)ds;
+            const bool ok = (16 * t + 4 * l4 + r < L) && (mrow < L);
+            pr[t][r] = ok ? __expf(s[t][r] * a.scale - lse) : 0.f;
+            delta += pr[t][r] * dp[t][r];  // sum_j P dP = dO . O
         }
+    delta += __shfl_xor(delta, 16, 64);
+    delta += __shfl_xor(delta, 32, 64);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ds[r] = pr[t][r] * (dp[t][r] - delta) * a.scale;
+        Pack<T, 4>::store(reinterpret_cast<T*>(Ps + (size_t)mrow * tstride) + 16 * t + 4 * l4, pr[t]);
+        Pack<T, 4>::store(reinterpret_cast<T*>(Ds + (size_t)mrow * tstride) + 16 * t + 4 * l4, ds);
     }
     __syncthreads();
 #pragma unroll
@@ -797,21 +817,29 @@ __global__ __launch_bounds__(256) void window_attn_bwd_tr_kernel(AttnArgs a) {
 #pragma unroll
             for (int k0 = 0; k0 < 64; k0 += 32) {
                 // dV[j][d] = sum_m P[m][j] dO[m][d] ; dK[j][d] = sum_m dS[m][j] Q[m][d]   (k = m: both operands transposed reads)
-                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Ps, tstride, k0, 16 * wv, lane), attn_tr_frag(Os, rstride, k0, 16 * dt, lane), dv, 0, 0, 0);
-                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Ds, tstride, k0, 16 * wv, lane), attn_tr_frag(Qs, rstride, k0, 16 * dt, lane), dk, 0, 0, 0);
-                // dQ[m][d] = sum_j dS[m][j] K[j][d]   (A: rows of dS, k = j contiguous; B: transposed read of K)
+                // (operands in this order - the d-indexed fragment first - so that a lane's four values are four CONSECUTIVE channels of one
+                // row: one 8-byte store per matrix and tile instead of four 2-byte stores to four rows)
+                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Os, rstride, k0, 16 * dt, lane), attn_tr_frag(Ps, tstride, k0, 16 * wv, lane), dv, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Qs, rstride, k0, 16 * dt, lane), attn_tr_frag(Ds, tstride, k0, 16 * wv, lane), dk, 0, 0, 0);
+                // dQ[m][d] = sum_j dS[m][j] K[j][d]   (rows of dS, k = j contiguous; transposed read of K)
                 const bf16x8 af = *reinterpret_cast<const bf16x8*>(Ds + (size_t)(16 * wv + l15) * tstride + (k0 + 8 * l4) * 2);
-                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af, attn_tr_frag(Ks, rstride, k0, 16 * dt, lane), dq, 0, 0, 0);
+                dq = __builtin_amdgcn_mfma_f32_16x16x32_bf16(attn_tr_frag(Ks, rstride, k0, 16 * dt, lane), af, dq, 0, 0, 0);
             }
-            const int d = dt * 16 + l15;
+            const int d = dt * 16 + 4 * l4, row = wv * 16 + l15;  // row: key j for dV / dK, query m for dQ
+            if (row < L) {
+                T* dst = dqkv + (int64_t)row * a.dqkv.ld + co + d;
+                if (vec4 && d + 3 < a.hd) {
+                    *reinterpret_cast<bf16x4*>(dst + 2 * a.C) = bf16x4{(T)dv[0], (T)dv[1], (T)dv[2], (T)dv[3]};
+                    *reinterpret_cast<bf16x4*>(dst + a.C) = bf16x4{(T)dk[0], (T)dk[1], (T)dk[2], (T)dk[3]};
+                    *reinterpret_cast<bf16x4*>(dst) = bf16x4{(T)dq[0], (T)dq[1], (T)dq[2], (T)dq[3]};
+                } else {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int row = wv * 16 + 4 * l4 + r;  // key j for dV/dK, query m for dQ
-                if (row < L && d < a.hd) {
-                    T* dst = dqkv + (int64_t)row * a.dqkv.ld + co + d;
-                    dst[2 * a.C] = (T)dv[r];
-                    dst[a.C] = (T)dk[r];
-                    dst[0] = (T)dq[r];
+                    for (int r = 0; r < 4; ++r)
+                        if (d + r < a.hd) {
+                            dst[2 * a.C + r] = (T)dv[r];
+                            dst[a.C + r] = (T)dk[r];
+                            dst[r] = (T)dq[r];
+                        }
                 }
             }
         }
