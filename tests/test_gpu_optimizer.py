@@ -206,9 +206,12 @@ def test_train_steps_match_reference_trainer_fixture(name, fixture, lr, momentum
     assert step.ema.updates == meta["ema_updates"]
 
 
-def test_graph_replay_follows_lr_schedule():
+@pytest.mark.parametrize("optimizer,lr", [("SGD", 0.01), ("AdamW", 0.002)])
+def test_graph_replay_follows_lr_schedule(optimizer, lr):
     """a captured step reads its learning rates from the device array: changing param_groups between replays changes
-    the update exactly as in eager mode (the lr float used to be baked into the captured optimizer)."""
+    the update exactly as in eager mode (the lr float used to be baked into the captured optimizer).  AdamW: its step
+    count and bias corrections live on the device too, so the replayed steps take t = 4, 5, ... like the eager ones (a weight decay of
+    lr * wd = 0 stops the decoupled decay as well when lr = 0)."""
     from improving_yolov8_cbam_swinblock_amd.engine.trainer import TrainStep, synthetic_batch
     from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
 
@@ -216,14 +219,14 @@ def test_graph_replay_follows_lr_schedule():
     for mode in ("eager", "graph"):
         torch.manual_seed(0)
         model = DetectionModel("yolov8n-cbam.yaml", ch=3, nc=1).to(dev())
-        step = TrainStep(model, world_size=1, lr=0.01, graph=(mode == "graph"))
+        step = TrainStep(model, world_size=1, lr=lr, graph=(mode == "graph"), optimizer=optimizer, momentum=0.937 if optimizer == "SGD" else 0.9)
         batch = synthetic_batch(2, 320, dev(), 1)
         if mode == "eager":  # graph mode runs 3 eager warm-up steps inside its first call
             for _ in range(3):
                 step(batch)
         for i in range(8):
             for grp in step.opt.param_groups:
-                grp["lr"] = 0.01 if i < 5 else 0.0   # from step 5 on the parameters must stop moving
+                grp["lr"] = lr if i < 5 else 0.0   # from step 5 on the parameters must stop moving
             step(batch)
             if i == 4:
                 torch.cuda.synchronize()
@@ -233,7 +236,7 @@ def test_graph_replay_follows_lr_schedule():
         del step, model
     for mode in ("eager", "graph"):
         assert torch.equal(out[mode][0], out[mode][1]), f"{mode}: parameters moved with lr = 0"
-    assert rel(out["graph"][1], out["eager"][1]) < 5e-3
+    assert rel(out["graph"][1], out["eager"][1]) < (5e-3 if optimizer == "SGD" else 2e-2)  # (AdamW's sign-like early steps amplify bf16 differences)
 
 
 def test_static_batch_shape_is_checked_in_graph_mode():

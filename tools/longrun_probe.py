@@ -1,12 +1,13 @@
 """Development probe: 300 graph-replayed training steps on four rotating synthetic batches (bs 32, 640x640, bf16): the
-three loss terms must fall and every parameter / buffer must stay finite."""
+three loss terms must fall and every parameter / buffer must stay finite.  YMI_PROBE_OPT=AdamW (lr 0.002) runs the AdamW branch."""
 import torch, sys, os
 sys.path.insert(0, os.getcwd())
 from improving_yolov8_cbam_swinblock_amd.engine.trainer import TrainStep, synthetic_batch
 from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
 dev = torch.device("cuda:0"); torch.manual_seed(0)
 model = DetectionModel("yolov8s.yaml", ch=3, nc=1).to(dev)
-step = TrainStep(model, graph=True, lr=0.01)
+opt = os.environ.get("YMI_PROBE_OPT", "SGD")
+step = TrainStep(model, graph=True, lr=0.01 if opt == "SGD" else 0.002, optimizer=opt, momentum=0.937 if opt == "SGD" else 0.9)
 batches = [synthetic_batch(32, 640, dev, s) for s in range(4)]
 hist = []
 for i in range(300):
