@@ -12,6 +12,23 @@ struct RV {
     int64_t ld;
 };
 
+// four consecutive elements as they lie in memory (8 bytes of bfloat16, 16 bytes of float32) and their conversion
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+    typedef bf16x4 type;
+    static __device__ __forceinline__ void to_f32(const bf16x4& r, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
+    }
+};
+template <> struct Raw4<float> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ void to_f32(const f32x4& r, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = r[i];
+    }
+};
+
 // FN: 0 colsum(a)            -> s0 = sum a
 //     1 bn-act backward      -> dz = a * act'(z), z = (b-mean)*inv*gamma+beta ; s0 = sum dz, s1 = sum dz*xhat
 //     2 layernorm param grads-> s0 = sum a (dbeta), s1 = sum a * (b - mean_row)*rstd_row (dgamma); mean/rstd per ROW
@@ -60,16 +77,38 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const f
             }
         };
         int64_t p = p0 + ty;
-        // 4 pixels per trip: 8 independent 8/16-byte loads in flight per lane before the first use
-        for (; p + 3 * (int64_t)rows < p1; p += 4 * (int64_t)rows) {
+        // 4 pixels per trip: 8 independent 8/16-byte loads in flight per lane before the first use; the NEXT trip's loads are issued
+        // (raw, unconverted: 2 VGPRs each in bf16) before this trip's arithmetic, so a workgroup with several trips does not pay one
+        // full memory round trip per trip (4 waves per SIMD are not enough to hide it: the arithmetic of a trip is as long as its loads)
+        typedef typename Raw4<T>::type R4;
+        R4 ra[4], rb[4];
+        bool have = p + 3 * (int64_t)rows < p1;
+        if (have) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ra[u] = *reinterpret_cast<const R4*>(ap + (p + u * (int64_t)rows) * a.ld + tx * 4);
+                if (FN != 0) rb[u] = *reinterpret_cast<const R4*>(bp + (p + u * (int64_t)rows) * b.ld + tx * 4);
+            }
+        }
+        while (have) {
             float va[4][4], vb[4][4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                Pack<T, 4>::load(ap + (p + u * (int64_t)rows) * a.ld + tx * 4, va[u]);
-                if (FN != 0) Pack<T, 4>::load(bp + (p + u * (int64_t)rows) * b.ld + tx * 4, vb[u]);
+                Raw4<T>::to_f32(ra[u], va[u]);
+                if (FN != 0) Raw4<T>::to_f32(rb[u], vb[u]);
+            }
+            const int64_t pc = p;
+            p += 4 * (int64_t)rows;
+            have = p + 3 * (int64_t)rows < p1;
+            if (have) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ra[u] = *reinterpret_cast<const R4*>(ap + (p + u * (int64_t)rows) * a.ld + tx * 4);
+                    if (FN != 0) rb[u] = *reinterpret_cast<const R4*>(bp + (p + u * (int64_t)rows) * b.ld + tx * 4);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) accum(va[u], vb[u], p + u * (int64_t)rows);
+            for (int u = 0; u < 4; ++u) accum(va[u], vb[u], pc + u * (int64_t)rows);
         }
         for (; p < p1; p += rows) {
             float va[4], vb[4];
