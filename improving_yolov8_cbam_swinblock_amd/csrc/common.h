@@ -103,6 +103,23 @@ template <> struct Pack<bf16_t, 8> {
 };
 
 // e^x as one v_exp_f32 (2^(x*log2 e)): ~1 ulp, results below 2^-126 flush to zero; no range-reduction code
+// four consecutive elements as they lie in memory (8 bytes of bfloat16, 16 bytes of float32) and their conversion
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+    typedef bf16x4 type;
+    static __device__ __forceinline__ void to_f32(const bf16x4& r, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
+    }
+};
+template <> struct Raw4<float> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ void to_f32(const f32x4& r, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = r[i];
+    }
+};
+
 // Workgroups are dealt round-robin to the 8 XCDs (flat id & 7), each with its own L2.  Work units that read neighbouring bytes
 // (the 16-byte channel chunks of one 128-byte line, the heads of one token row) should therefore NOT sit on consecutive flat
 // ids: every XCD would fetch the whole line.  xcd_unit() turns the flat workgroup id into a work-unit index such that

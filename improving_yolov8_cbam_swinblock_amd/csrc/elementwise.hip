@@ -475,16 +475,37 @@ __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const 
     };
     const int64_t step = (int64_t)gridDim.x * rows_per_block;
     int64_t p = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / groups;
-    // 4 pixels per trip: the loads of all four are in flight before the first use
-    for (; p + 3 * step < P; p += 4 * step) {
+    // 4 pixels per trip: the loads of all four are in flight before the first use, and the NEXT trip's (raw) loads are issued before this
+    // trip's arithmetic (as in the BatchNorm backward passes, csrc/reduce_bwd.hip)
+    typedef typename Raw4<T>::type R4;
+    R4 rv[4], rres[4];
+    bool have = p + 3 * step < P;
+    if (have) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            rv[u] = *reinterpret_cast<const R4*>(xp + (p + u * step) * x.ld + g * 4);
+            if (rp) rres[u] = *reinterpret_cast<const R4*>(rp + (p + u * step) * res.ld + g * 4);
+        }
+    }
+    while (have) {
         float v[4][4], rr[4][4] = {};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            Pack<T, 4>::load(xp + (p + u * step) * x.ld + g * 4, v[u]);
-            if (rp) Pack<T, 4>::load(rp + (p + u * step) * res.ld + g * 4, rr[u]);
+            Raw4<T>::to_f32(rv[u], v[u]);
+            if (rp) Raw4<T>::to_f32(rres[u], rr[u]);
+        }
+        const int64_t pc = p;
+        p += 4 * step;
+        have = p + 3 * step < P;
+        if (have) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rv[u] = *reinterpret_cast<const R4*>(xp + (p + u * step) * x.ld + g * 4);
+                if (rp) rres[u] = *reinterpret_cast<const R4*>(rp + (p + u * step) * res.ld + g * 4);
+            }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) one(v[u], rr[u], p + u * step);
+        for (int u = 0; u < 4; ++u) one(v[u], rr[u], pc + u * step);
     }
     for (; p < P; p += step) {
         float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};

@@ -12,23 +12,6 @@ struct RV {
     int64_t ld;
 };
 
-// four consecutive elements as they lie in memory (8 bytes of bfloat16, 16 bytes of float32) and their conversion
-template <typename T> struct Raw4;
-template <> struct Raw4<bf16_t> {
-    typedef bf16x4 type;
-    static __device__ __forceinline__ void to_f32(const bf16x4& r, float (&v)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
-    }
-};
-template <> struct Raw4<float> {
-    typedef f32x4 type;
-    static __device__ __forceinline__ void to_f32(const f32x4& r, float (&v)[4]) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = r[i];
-    }
-};
-
 // FN: 0 colsum(a)            -> s0 = sum a
 //     1 bn-act backward      -> dz = a * act'(z), z = (b-mean)*inv*gamma+beta ; s0 = sum dz, s1 = sum dz*xhat
 //     2 layernorm param grads-> s0 = sum a (dbeta), s1 = sum a * (b - mean_row)*rstd_row (dgamma); mean/rstd per ROW
@@ -328,15 +311,49 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
         constexpr int U = G == 8 ? 2 : 4;  // pixels per trip: 2*U independent loads in flight per lane
         const int64_t step = (int64_t)gridDim.x * rows;
         int64_t p = (int64_t)blockIdx.x * rows + threadIdx.x / groups;
-        for (; p + (U - 1) * step < P; p += U * step) {
-            float d[U][G], x[U][G];
+        if constexpr (G == 4) {
+            // as in chan_reduce_kernel: the next trip's (raw) loads are in flight while this trip's arithmetic runs
+            typedef typename Raw4<T>::type R4;
+            R4 rd[U], rx[U];
+            bool have = p + (U - 1) * step < P;
+            if (have) {
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                Pack<T, G>::load(dp + (p + u * step) * dout.ld + g * G, d[u]);
-                Pack<T, G>::load(rp + (p + u * step) * raw.ld + g * G, x[u]);
+                for (int u = 0; u < U; ++u) {
+                    rd[u] = *reinterpret_cast<const R4*>(dp + (p + u * step) * dout.ld + g * G);
+                    rx[u] = *reinterpret_cast<const R4*>(rp + (p + u * step) * raw.ld + g * G);
+                }
             }
+            while (have) {
+                float d[U][G], x[U][G];
 #pragma unroll
-            for (int u = 0; u < U; ++u) one(d[u], x[u], p + u * step);
+                for (int u = 0; u < U; ++u) {
+                    Raw4<T>::to_f32(rd[u], d[u]);
+                    Raw4<T>::to_f32(rx[u], x[u]);
+                }
+                const int64_t pc = p;
+                p += U * step;
+                have = p + (U - 1) * step < P;
+                if (have) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        rd[u] = *reinterpret_cast<const R4*>(dp + (p + u * step) * dout.ld + g * G);
+                        rx[u] = *reinterpret_cast<const R4*>(rp + (p + u * step) * raw.ld + g * G);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) one(d[u], x[u], pc + u * step);
+            }
+        } else {
+            for (; p + (U - 1) * step < P; p += U * step) {
+                float d[U][G], x[U][G];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    Pack<T, G>::load(dp + (p + u * step) * dout.ld + g * G, d[u]);
+                    Pack<T, G>::load(rp + (p + u * step) * raw.ld + g * G, x[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) one(d[u], x[u], p + u * step);
+            }
         }
         for (; p < P; p += step) {
             float d[G], x[G];
