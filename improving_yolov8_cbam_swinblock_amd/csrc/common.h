@@ -135,10 +135,28 @@ __device__ __forceinline__ float silu_grad_f(float x) {
     float s = sigmoidf_(x);
     return s * (1.0f + x * (1.0f - s));
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// erf(z) by Abramowitz & Stegun 7.1.26: 1 - (a1 t + .. + a5 t^5) e^(-z^2), t = 1 / (1 + p |z|); absolute error <= 1.5e-7 - float32 noise
+// next to the 1 the GELU adds it to - in 6 multiply-adds, v_rcp_f32 and v_exp_f32.  libm's erff is ~45 instructions with two branches
+// that a wave executes both of; in the Swin MLP's GEMM epilogues (32768 activations per 256 x 128 tile) that was as long as the K loop.
+// e2 (optional): receives e^(-z^2), which GELU's derivative needs as well.
+__device__ __forceinline__ float erf_as(float z, float* e2 = nullptr) {
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+    const float e = fast_exp(-az * az);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    if (e2) *e2 = e;
+    return copysignf(1.0f - p * t * e, z);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     const float c = 0.39894228040143267794f;  // 1/sqrt(2 pi)
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * c * fast_exp(-0.5f * x * x);
+    float e;                                   // e^(-x^2 / 2)
+    const float er = erf_as(x * 0.70710678118654752440f, &e);
+    return 0.5f * (1.0f + er) + x * c * e;
 }
 template <int ACT> __device__ __forceinline__ float apply_act(float x) {
     if (ACT == YMI_ACT_SILU) return silu_f(x);
