@@ -199,7 +199,9 @@ def test_train_steps_match_reference_trainer_fixture(name, fixture, lr, momentum
         items = step(batch)
         torch.cuda.synchronize()
         # step 0: identical weights on both sides; step 1: weights 1e-7 apart, amplified by the tiny model's 2-image BatchNorm
-        assert abs(step.opt.grad_norm() - meta["norms"][i]) <= (1e-3, 1e-2)[i] * meta["norms"][i]
+        # (AdamW: the first update is lr * g / (|g| + 1e-8) - a gradient entry within float32 noise of zero takes a full-size step in a
+        # direction that noise decides - so its second step starts from weights that differ in those entries: 5e-2 on the second norm)
+        assert abs(step.opt.grad_norm() - meta["norms"][i]) <= ((1e-3, 1e-2) if name == "SGD" else (1e-3, 5e-2))[i] * meta["norms"][i]
         states.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
         ema_states.append({k: v.detach().cpu().clone() for k, v in step.ema.ema.state_dict().items()})
     check_update_steps(d, init, states, ema_states, step_tol=(2e-3, 5e-2) if name == "SGD" else (2e-2, 1e-1))
