@@ -541,6 +541,32 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
     const T* zero = reinterpret_cast<const T*>(a.zero);
 
+    // ---- warm this XCD's L2 with the weight rows of this N block ---------------------------------------------------------------------
+    // Inside the training step a layer's packed weights are NOT in L2 (they were written at the start of the step), and every workgroup
+    // walks K in the same order: each K step's weight lines miss once per XCD with everybody waiting on that one fill - K / 64 serialized
+    // memory latencies per launch (det.cv2[2].0, K = 4608: 21 us with warm caches, 52 us in the step and with evicted caches in
+    // tools/conv_bench.py --cold - 33-35 us in the step with this warm-up; the data gradients, K <= 1152, barely notice).  So the first workgroups of an XCD touch every 128-byte
+    // line of their N block's rows up front, all requests in flight at once - as 4-byte LDS-DMA loads into the first bytes of the ring:
+    // no register receives the data (a VGPR destination made the register allocator wait for the loads at once, and an inline-asm load
+    // is simply wrong: the compiler reuses the register before the data lands).  A wave's loads complete in order - ONLY a wave's own: the
+    // bytes a wave aims at are the first ones its own first A-row load of stage 0 writes (wave * 64 chunks of 16 bytes), so that load,
+    // issued later by the same wave, overwrites them before anything reads them; the counted waits of the K loop are unaffected.
+    {
+        const int rows_valid = (a.Cout - n0 < BN) ? a.Cout - n0 : BN;
+        const uint32_t lines = (uint32_t)(((int64_t)rows_valid * a.ktot * (int64_t)sizeof(T) + 127) >> 7);
+        const uint32_t pw = (lines + 4 * NT - 1) / (4 * NT);  // workgroups needed at 4 lines per thread
+        if ((uint32_t)ml < pw) {  // (workgroup-uniform)
+            const char* wbase = reinterpret_cast<const char*>(wg + (int64_t)n0 * a.ktot);
+            const uint32_t last = lines - 1, st = pw * NT;
+            uint32_t li = (uint32_t)ml * NT + (uint32_t)tid_all;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {  // (lines beyond the last one re-touch it: every lane of a wave issues, as LDS-DMA requires)
+                __builtin_amdgcn_global_load_lds((gptr_t)(wbase + (size_t)(li < last ? li : last) * 128), (lptr_t)(smem + wave * 64 * 16), 4, 0, 0);
+                li += st;
+            }
+        }
+    }
+
     // ---- per-thread load descriptors -----------------------------------------------------------
     // source chunk of the K step this thread fetches: LDS position (row, tid % CPR) holds chunk pos ^ f(row)
     const int c = CPR == 4 ? ((tid & 3) ^ ((-(tid >> 4)) & 3)) : ((tid & 7) ^ ((tid >> 4) & 7));

@@ -90,6 +90,7 @@ def main():
     ap.add_argument("--only", default="", help="substring filter on the shape name")
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
     ap.add_argument("--shape", action="append", default=[], help="extra shape 'name,cin,cout,k,stride,H' (square map; replaces the model's list)")
+    ap.add_argument("--cold", action="store_true", help="evict the caches (1 GiB fill) before every timed launch: per-launch events, as a layer meets its operands inside the step")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DYMI_STAMPS) only: print the s_memtime stamps of one workgroup's K steps")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -144,13 +145,27 @@ def main():
                 continue
             for _ in range(3):
                 fn()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(args.iters):
-                fn()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) * 1e3 / args.iters
+            if args.cold:
+                if "evict" not in globals():
+                    globals()["evict"] = torch.empty(1 << 28, dtype=torch.float32, device=dev)  # 1 GiB > L2 + Infinity Cache
+                tot_ms = 0.0
+                for _ in range(args.iters):
+                    globals()["evict"].fill_(1.0)
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                    fn()
+                    e1.record()
+                    torch.cuda.synchronize()
+                    tot_ms += e0.elapsed_time(e1)
+                us = tot_ms * 1e3 / args.iters
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    fn()
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) * 1e3 / args.iters
             if args.stamps:
                 stamp_dump(L, fn, f"{name} {nm} ({us:.1f} us)", nm == "wgrad")
             tot[nm] += us * count
