@@ -214,6 +214,9 @@ def main():
                     help="torch.distributed backend of the gradient mean: nccl (= RCCL over xGMI, the measured configuration) or gloo "
                          "(rehearsal of the multi-rank path on fewer GPUs than ranks: ranks then share devices round-robin)")
     ap.add_argument("--sustained", type=int, default=200, help="graph replays of the sustained-throughput sub-record (0: skip)")
+    ap.add_argument("--forward-only", action="store_true",
+                    help="profiling aid: run ONLY the train-mode forward (north_star's target metric) - warm-up + `steps` graph replays - and print "
+                         "its record; under rocprofv3 --kernel-trace --stats this gives the forward's own kernel table")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -242,8 +245,14 @@ def main():
     model = DetectionModel(args.model, ch=3, nc=1).to(dev)
     ddp.broadcast_parameters(model)
     use_graph = bool(args.graph)
-    step = TrainStep(model, world_size=world, graph=use_graph)
     batch = synthetic_batch(args.batch, args.imgsz, dev, ddp.shard_seed(1, rank))
+    if args.forward_only:
+        gf_fwd, _ = gflop_per_img(args.model, args.imgsz)
+        rec = forward_record(model, batch, args.steps, gf_fwd or 0.0)
+        rec["model"] = args.model
+        print(json.dumps({"forward": rec}), flush=True)
+        return
+    step = TrainStep(model, world_size=world, graph=use_graph)
 
     for _ in range(args.warmup):
         step(batch)

@@ -247,7 +247,7 @@ def _conv_out_hw(h, w, k, s):
 
 def _wgrad(x, dy, cout, cin, k, stride, want_bias, params=()):
     """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None).  params: the parameters these gradients belong to."""
-    if _deferred["on"] and _in_backward() and _adoptable(params):
+    if _deferred["on"] and _in_backward() and _adoptable(params) and not _deferred_twice(params):
         return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, params[0] if params else None)
     dev = x.device
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
@@ -265,9 +265,23 @@ def _adoptable(params):
     for p in params:
         if p is None:
             continue
+        if not p.requires_grad:
+            # autograd drops the returned tensor at once: a deferred slab sum would later write into memory the allocator has
+            # already handed to another tensor of the pass (round-3 ADVICE)
+            return False
         if p.grad is not None or getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
             return False
     return True
+
+
+def _deferred_twice(params):
+    """True when one of these parameters already has a deferred gradient in THIS pass (a weight used twice in one graph): autograd
+    would sum the two still unfilled tensors before AccumulateGrad runs, and both slab sums would then overwrite the same `.grad`
+    instead of accumulating - the second use gets its complete gradient at once (round-3 ADVICE)."""
+    if _deferred["task"] != torch._C._current_graph_task_id():
+        return False
+    seen = _deferred["owner_ids"]
+    return any(p is not None and id(p) in seen for p in params)
 
 
 def _in_backward():
@@ -345,7 +359,7 @@ def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias, params=()):
 # So the deferral is OPT-IN: engine.trainer.TrainStep, which zeroes gradients with set_to_none=True after every step and
 # knows its DDP schedule, enables it around its backward.  Everywhere else (plain autograd use of the modules, gradient
 # accumulation, hooks) each weight gradient is complete when its Function returns.
-_deferred = {"on": False, "records": [], "keep": [], "owners": [], "task": None, "table": None}
+_deferred = {"on": False, "records": [], "keep": [], "owners": [], "owner_ids": set(), "task": None, "table": None}
 
 
 class deferred_wgrad:
@@ -373,6 +387,7 @@ def set_wgrad_deferred(flag):
 def _flush_wgrads():
     recs, keep, owners = _deferred["records"], _deferred["keep"], _deferred["owners"]
     _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["task"] = [], [], [], None
+    _deferred["owner_ids"] = set()
     if not recs:
         return
     # Every node of the pass has run: a parameter's AccumulateGrad has either ADOPTED the returned tensor (p.grad is that
@@ -406,6 +421,7 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
         # first deferred gradient of this pass.  Records of an earlier pass whose end-of-pass callback never ran (the engine
         # drops callbacks when a backward raises) are stale: their gradient tensors are gone - discard them.
         _deferred["records"], _deferred["keep"], _deferred["owners"] = [], [], []
+        _deferred["owner_ids"] = set()
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
         _deferred["task"] = task
     dev = x.device
@@ -420,6 +436,8 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
     _deferred["records"].append(rec)
     _deferred["keep"].append((ws, x, dy))
     _deferred["owners"].append(owner)
+    if owner is not None:
+        _deferred["owner_ids"].add(id(owner))
     return dw, (db[:cout] if want_bias else None)
 
 
@@ -631,7 +649,9 @@ class _ConvBnAct(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _dgrad_joined(join, draw, weight, k, stride, x.shape, dtype)
-        dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False, (weight,))
+        dw = None
+        if ctx.needs_input_grad[1]:  # (a frozen conv weight: no GEMM, and nothing for a deferred slab sum to write into)
+            dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False, (weight,))
         return dx, dw, dgamma, dbeta, None, None, None, None, None, None, dres, None, None, None
 
 
@@ -745,8 +765,13 @@ class _ConvAffineAct(torch.autograd.Function):
                 if adds is None:
                     join.deposit(dx)
                     dx = None
-        dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias, (weight, ctx.bias_param))
-        dw = dw.view(weight.shape)
+        dw = db = None
+        need_w, need_b = ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[3]
+        if need_w or need_b:
+            # (the bias gradient comes out of the same launch; a frozen weight with a trainable bias gets its complete, un-deferred result)
+            dw, db = _wgrad_maybe_async(x, dy, o, cin, k, stride, has_bias, (weight, ctx.bias_param))
+            dw = dw.view(weight.shape) if need_w else None
+            db = db if need_b else None
         return dx, dw, None, db, None, None, dres, None, None, None
 
 
@@ -865,9 +890,15 @@ class _SwinMlp(torch.autograd.Function):
             if adds is None:
                 join.deposit(du)
                 du = None
-        dw2, db2 = _wgrad_maybe_async(post, dout, w2.shape[0], hidden, 1, 1, has_b2, (w2, ctx.biases[1]))
-        dw1, db1 = _wgrad_maybe_async(u, dpre, hidden, c, 1, 1, has_b1, (w1, ctx.biases[0]))
-        return du, dw1.view(w1.shape), db1, dw2.view(w2.shape), db2, dres, None, None
+        nig = ctx.needs_input_grad  # (u, w1, b1, w2, b2, ...): frozen parameters get no GEMM and no deferred record
+        dw1 = db1 = dw2 = db2 = None
+        if nig[3] or (has_b2 and nig[4]):
+            dw2, db2 = _wgrad_maybe_async(post, dout, w2.shape[0], hidden, 1, 1, has_b2, (w2, ctx.biases[1]))
+            dw2, db2 = (dw2.view(w2.shape) if nig[3] else None), (db2 if nig[4] else None)
+        if nig[1] or (has_b1 and nig[2]):
+            dw1, db1 = _wgrad_maybe_async(u, dpre, hidden, c, 1, 1, has_b1, (w1, ctx.biases[0]))
+            dw1, db1 = (dw1.view(w1.shape) if nig[1] else None), (db1 if nig[2] else None)
+        return du, dw1, db1, dw2, db2, dres, None, None
 
 
 def swin_mlp(u, fc1, fc2, residual=None):

@@ -214,3 +214,51 @@ def test_bench_two_ranks_gloo_as_a_child_process():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4 and d["config"]["backend"] == "gloo"
     assert d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and all(v == v for v in d["loss_items"])
+
+
+def test_frozen_mid_network_conv_gets_no_deferred_weight_gradient():
+    """a Conv weight with requires_grad=False whose input still needs a gradient (round-3 ADVICE): autograd drops the tensor a
+    weight-gradient Function returns for it at once, so a DEFERRED slab sum would later write into memory the allocator has handed to
+    another gradient of the same pass.  Frozen weights get no GEMM and no record; every other gradient equals the non-deferred pass."""
+    from improving_yolov8_cbam_swinblock_amd import ops
+
+    model, batch = _small_model()
+    frozen = [model.model[4].cv1.conv.weight, model.model[6].m[0].cv2.conv.weight, model.model[-1].cv3[1][2].weight]
+    for p in frozen:
+        p.requires_grad_(False)
+    stats = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    _backward(model, batch)  # immediate, complete gradients
+    ref = _grads(model)
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(stats, strict=False)
+    with ops.deferred_wgrad(True):
+        _backward(model, batch)
+    got = _grads(model)
+    assert all(p.grad is None for p in frozen)
+    assert set(got) == set(ref) and len(ref) > 100
+    bad = [(n, rel(got[n], ref[n])) for n in ref if not rel(got[n], ref[n]) <= 1e-5]
+    assert not bad, bad[:5]
+    # the frozen Detect output conv keeps its trainable bias: that gradient is still produced
+    assert model.model[-1].cv3[1][2].bias.grad is not None
+
+
+def test_weight_used_twice_in_one_pass_accumulates_both_gradients():
+    """one Conv applied twice in a graph (round-3 ADVICE, low): with deferral on, the second use must not be deferred as well - both
+    slab sums would overwrite the same .grad.  The total equals the non-deferred result."""
+    from improving_yolov8_cbam_swinblock_amd import ops
+    from improving_yolov8_cbam_swinblock_amd.nn.modules import Conv
+
+    torch.manual_seed(3)
+    conv = Conv(32, 32, 3, 1).to(dev()).train()
+    x = torch.randn(2, 32, 20, 20, device=dev())
+
+    def run(deferred):
+        conv.zero_grad(set_to_none=True)
+        with ops.deferred_wgrad(deferred):
+            y = conv(conv(x))
+            y.float().square().mean().backward()
+        torch.cuda.synchronize()
+        return conv.conv.weight.grad.detach().clone()
+
+    g0, g1 = run(False), run(True)
+    assert rel(g1, g0) <= 1e-5, rel(g1, g0)
