@@ -13,7 +13,8 @@ import torch
 
 PKG_DIR = Path(__file__).resolve().parent
 CSRC_DIR = PKG_DIR / "csrc"
-LIB_PATH = PKG_DIR / "libyolo_mi355.so"
+# YMI_LIB=<path>: development aid for same-box A/B runs of two builds of the library (same C ABI); unset: the in-tree build
+LIB_PATH = Path(os.environ["YMI_LIB"]).resolve() if os.environ.get("YMI_LIB") else PKG_DIR / "libyolo_mi355.so"
 
 YMI_F32, YMI_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2

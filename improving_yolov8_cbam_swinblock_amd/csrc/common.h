@@ -124,6 +124,34 @@ template <> struct Raw4<float> {
 // (the 16-byte channel chunks of one 128-byte line, the heads of one token row) should therefore NOT sit on consecutive flat
 // ids: every XCD would fetch the whole line.  xcd_unit() turns the flat workgroup id into a work-unit index such that
 // consecutive UNITS run on one XCD, back to back (a permutation of [0, total) when total % 8 == 0, the identity otherwise).
+// ---- XCD ownership of the pixel axis (round 4) -----------------------------------------------------------------------------------
+// A consumer finds its producer's bytes in its own XCD's L2 - 3.7-6x faster for a latency-shaped reader such as a GEMM's operand
+// ring than from another XCD's L2 / the Infinity Cache (profiles/r04_xcd_affinity_probe.txt) - when both kernels give an XCD the
+// same part of the tensor.  ONE rule for every kernel that walks pixels (or tokens): the XCD a workgroup runs on (flat id & 7:
+// workgroups are dealt round-robin, measured stable from launch to launch) owns the pixels [x * span, (x + 1) * span) of the
+// batch-major pixel order, span = ymi_xcd_span(P).  The rule is a FRACTION of the pixel order, so it lines up across resolutions
+// (a stride-2 consumer's eighth of the output reads the same eighth of its input), and at batch sizes that are multiples of 8 it is
+// whole images.  Placement is a speed matter only: nothing depends on it for correctness.
+__host__ __device__ __forceinline__ int64_t ymi_xcd_span(int64_t P) { return (((P + 63) >> 6) + 7) >> 3 << 6; }
+// the pixel range [lo, hi) of this workgroup's XCD, the workgroup's index among that XCD's workgroups and their number
+// (the launch grid must be a multiple of 8 workgroups)
+struct XcdRange {
+    int64_t lo, hi;
+    int bi, nbx;
+};
+int64_t ymi_xcd_span_arg(int64_t P);  // host: ymi_xcd_span(P), with the diagnostic shift of YMI_XCD_SHIFT in bits 56..58
+__device__ __forceinline__ XcdRange xcd_range(int64_t P, int64_t span_arg) {
+    const int id = blockIdx.x, x = ((id & 7) + (int)(span_arg >> 56)) & 7;
+    const int64_t span = span_arg & ((1ll << 56) - 1);
+    XcdRange r;
+    r.lo = x * span;
+    r.hi = r.lo + span < P ? r.lo + span : P;
+    if (r.lo > P) r.lo = P;
+    r.bi = id >> 3;
+    r.nbx = gridDim.x >> 3;
+    return r;
+}
+
 __device__ __forceinline__ int xcd_unit(int flat, int total) { return (total & 7) ? flat : (flat & 7) * (total >> 3) + (flat >> 3); }
 __device__ __forceinline__ int flat_block_id() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
 

@@ -456,7 +456,11 @@ __global__ void scale_shift_act_kernel(TV x, const float* __restrict__ scale, co
 // all its pixels and holds scale/shift in registers; 8-byte (bf16) / 16-byte (f32) accesses, coalesced along C.
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                    TV res, TV o, int groups, int64_t P) {
+                                                                    TV res, TV o, int groups, int64_t Pall, int64_t span) {
+    // pixels of this workgroup's XCD only (common.h, XCD ownership of the pixel axis): the GEMM that wrote `x` and the one that will read
+    // `o` give this XCD the same eighth
+    const XcdRange xr = xcd_range(Pall, span);
+    const int64_t P = xr.hi;
     const int g = threadIdx.x % groups;
     const int rows_per_block = 256 / groups;
     float sc[4], sh[4];
@@ -473,8 +477,8 @@ __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const 
         for (int r = 0; r < 4; ++r) v[r] = apply_act<ACT>(v[r] * sc[r] + sh[r]) + rr[r];
         Pack<T, 4>::store(op + p * o.ld + g * 4, v);
     };
-    const int64_t step = (int64_t)gridDim.x * rows_per_block;
-    int64_t p = (int64_t)blockIdx.x * rows_per_block + threadIdx.x / groups;
+    const int64_t step = (int64_t)xr.nbx * rows_per_block;
+    int64_t p = xr.lo + (int64_t)xr.bi * rows_per_block + threadIdx.x / groups;
     // 4 pixels per trip: the loads of all four are in flight before the first use, and the NEXT trip's (raw) loads are issued before this
     // trip's arithmetic (as in the BatchNorm backward passes, csrc/reduce_bwd.hip)
     typedef typename Raw4<T>::type R4;
@@ -526,10 +530,12 @@ static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const fl
     int64_t gb = (P + (int64_t)rows * ew_ppt() - 1) / ((int64_t)rows * ew_ppt());
     if (gb < 1024) gb = (P + rows - 1) / rows < 1024 ? (P + rows - 1) / rows : 1024;
     if (gb > ew_cap()) gb = ew_cap();  // default 2048: one resident round of 256-thread blocks on 256 CUs
+    gb = (gb + 7) / 8 * 8;             // the same number of workgroups on every XCD
+    const int64_t span = ymi_xcd_span_arg(P);
     dim3 g((unsigned)gb), b(256);
-    if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
-    else if (act == YMI_ACT_GELU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_GELU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
-    else hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_NONE>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P);
+    if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span);
+    else if (act == YMI_ACT_GELU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_GELU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span);
+    else hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_NONE>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span);
 }
 
 extern "C" int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, const float* shift, int32_t act, const ymi_tensor* residual,

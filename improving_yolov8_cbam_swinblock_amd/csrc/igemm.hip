@@ -90,7 +90,8 @@ struct IgemmArgs {
     uint64_t tap_dh, tap_dw;
     int act, vec_store, vec16;
     uint32_t wo_mul, wo_shr, ho_mul, ho_shr;  // fast division by Wo / Ho
-    int nmb, nnb, mpx;                        // M blocks, N blocks, M blocks per XCD (launch geometry, set by the launcher)
+    int nmb, nnb, mpx;                        // M blocks, N blocks, most M blocks any XCD owns (launch geometry, set by the launcher)
+    int span;                                 // rows of M an XCD owns: ymi_xcd_span(M) (common.h, XCD ownership of the pixel axis)
 };
 
 // Up to four problems in one launch (the four output-parity classes of a stride-2 data gradient): consecutive ids of an
@@ -529,13 +530,19 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     // CONTIGUOUS range of M blocks (neighbouring pixel tiles share 3x3 halo rows) and walks the N blocks of one M block
     // back to back, so the A tile an M block gathers is fetched into that XCD's L2 once and reused by all its N blocks
     // (with N blocks on grid.y they ran a whole grid apart and A came back from MALL/HBM once per N block).
-    // The 1-D grid is padded to 8 * mpx * nnb ids; ids that fall outside the M range leave before any barrier.
+    // The range is the XCD's EIGHTH of the pixel order (round 4): the kernel that produced the rows (a BatchNorm pass, another
+    // GEMM's epilogue) wrote that eighth from this XCD too, so they are in this L2, not in another one's.
+    // The 1-D grid is padded to 8 * mpx * nnb ids; ids that fall outside the XCD's range leave before any barrier.
     const int orig = blockIdx.x, xcd = orig & 7, seq0 = orig >> 3;
     const int cls = P.ncls > 1 ? seq0 % P.ncls : 0, seq = P.ncls > 1 ? seq0 / P.ncls : seq0;  // block-uniform
     const IgemmArgs a = P.c[cls];
     const int nb = seq % a.nnb, ml = seq / a.nnb;
-    const int mb = xcd * a.mpx + ml;
-    if (mb >= a.nmb) return;
+    // this XCD owns the M blocks whose first row lies in its span of the pixel order (the rule every streaming kernel follows, common.h)
+    const int first = (xcd * a.span + BM - 1) / BM;
+    int last = ((xcd + 1) * a.span + BM - 1) / BM;
+    last = last < a.nmb ? last : a.nmb;
+    const int mb = first + ml;
+    if (mb >= last) return;
     const int m0 = mb * BM, n0 = nb * BN;
     const T* __restrict__ xg = reinterpret_cast<const T*>(a.x);
     const T* __restrict__ wg = reinterpret_cast<const T*>(a.w);
@@ -891,7 +898,15 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
         P.c[i] = arr[i];
         P.c[i].nmb = (arr[i].M + t.bm - 1) / t.bm;
         P.c[i].nnb = (arr[i].Cout + t.bn - 1) / t.bn;
-        if ((P.c[i].nmb + 7) / 8 > mpx) mpx = (P.c[i].nmb + 7) / 8;
+        const int64_t span = ymi_xcd_span(arr[i].M);
+        YMI_CHECK_ARG(8 * span < (1ll << 31), "igemm: M too large");
+        P.c[i].span = (int)span;
+        for (int x = 0; x < 8; ++x) {  // as the kernel counts them
+            const int64_t first = (x * span + t.bm - 1) / t.bm;
+            int64_t last = ((x + 1) * span + t.bm - 1) / t.bm;
+            if (last > P.c[i].nmb) last = P.c[i].nmb;
+            if (last - first > mpx) mpx = (int)(last - first);
+        }
     }
     for (int i = 0; i < ncls; ++i) P.c[i].mpx = mpx;  // one id decode for all classes (same Cout => same nnb)
     const IgemmArgs& a = P.c[0];

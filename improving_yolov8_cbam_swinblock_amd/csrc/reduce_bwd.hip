@@ -16,15 +16,19 @@ struct RV {
 //     1 bn-act backward      -> dz = a * act'(z), z = (b-mean)*inv*gamma+beta ; s0 = sum dz, s1 = sum dz*xhat
 //     2 layernorm param grads-> s0 = sum a (dbeta), s1 = sum a * (b - mean_row)*rstd_row (dgamma); mean/rstd per ROW
 template <typename T, int FN, int ACT>
-__global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
+__global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part) {
     extern __shared__ float red[];  // [rows][TG][8]
     const int rows = 256 / TG;
     const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
     const int c0 = blockIdx.y * 1024;  // channels beyond 1024 go to further grid rows
     const int groups = ((C - c0 < 1024) ? C - c0 : 1024) / 4;
-    const int64_t per = (P + gridDim.x - 1) / gridDim.x;
-    const int64_t p0 = blockIdx.x * per, p1 = (p0 + per < P) ? p0 + per : P;
+    // a contiguous pixel range per workgroup, inside the eighth of the pixel order this workgroup's XCD owns (common.h: the kernel
+    // that wrote `a` - a data-gradient GEMM, the loss - and the apply pass / GEMMs that follow use the same eighths).  gridDim.x is a
+    // multiple of 8; the partial row of a workgroup stays blockIdx.x, and the final pass sums rows in index order: deterministic.
+    const XcdRange xr = xcd_range(P, span);
+    const int64_t per = (xr.hi - xr.lo + xr.nbx - 1) / xr.nbx;
+    const int64_t p0 = (xr.lo + xr.bi * per < xr.hi) ? xr.lo + xr.bi * per : xr.hi, p1 = (p0 + per < xr.hi) ? p0 + per : xr.hi;
     const T* ap = reinterpret_cast<const T*>(a.p) + c0;
     const T* bp = reinterpret_cast<const T*>(b.p) + c0;
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
@@ -214,7 +218,7 @@ static int reduce_blocks(int64_t P, int C) {
     int64_t b = (P + ppb - 1) / ppb;
     if (b > 1024) b = 1024;
     if (b < 1) b = 1;
-    return (int)b;
+    return (int)((b + 7) / 8 * 8);  // the same number of workgroups on every XCD (chan_reduce_kernel walks XCD-owned pixel ranges)
 }
 
 template <int FN>
@@ -228,7 +232,7 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
     const int blocks = reduce_blocks(P, C);
     const size_t lds = (size_t)256 * 8 * sizeof(float);
     RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
-#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, C, TG, gamma, beta, mean, inv, part)
+#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, ymi_xcd_span_arg(P), C, TG, gamma, beta, mean, inv, part)
 #define YMI_CR_T(T)                                                      \
     do {                                                                 \
         if (FN != 1 || act == YMI_ACT_NONE) YMI_CR(T, YMI_ACT_NONE);     \
@@ -282,8 +286,9 @@ int ymi_ln_param_grads(const ymi_tensor* dy, const ymi_tensor* x, const float* m
 // FIXED: the number of G-channel groups divides 256, so a thread keeps one channel group and its coefficients in
 // registers for all of its pixels.  G = 4 (8-byte bf16 / 16-byte f32 accesses) or 8 (bf16 only, 16-byte accesses).
 template <typename T, int G, bool FIXED, int ACT>
-__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t P, int C, const float* __restrict__ coef) {
+__global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, RV draw, int64_t Pall, int64_t span, int C, const float* __restrict__ coef) {
     const int groups = C / G;
+    int64_t P = Pall;
     const T* dp = reinterpret_cast<const T*>(dout.p);
     const T* rp = reinterpret_cast<const T*>(raw.p);
     T* op = reinterpret_cast<T*>(const_cast<void*>(draw.p));
@@ -309,8 +314,11 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
             Pack<T, G>::store(op + p * draw.ld + g * G, o);
         };
         constexpr int U = G == 8 ? 2 : 4;  // pixels per trip: 2*U independent loads in flight per lane
-        const int64_t step = (int64_t)gridDim.x * rows;
-        int64_t p = (int64_t)blockIdx.x * rows + threadIdx.x / groups;
+        // the pixels of this workgroup's XCD (common.h, XCD ownership of the pixel axis; the grid is a multiple of 8)
+        const XcdRange xr = xcd_range(Pall, span);
+        P = xr.hi;
+        const int64_t step = (int64_t)xr.nbx * rows;
+        int64_t p = xr.lo + (int64_t)xr.bi * rows + threadIdx.x / groups;
         if constexpr (G == 4) {
             // as in chan_reduce_kernel: the next trip's (raw) loads are in flight while this trip's arithmetic runs
             typedef typename Raw4<T>::type R4;
@@ -401,8 +409,10 @@ static int launch_bn_apply(const ymi_tensor* dout, const ymi_tensor* raw, const 
         gb = (total + 255) / 256;
     }
     if (gb > ew_cap()) gb = ew_cap();
+    gb = (gb + 7) / 8 * 8;
+    const int64_t span = ymi_xcd_span_arg(P);
     RV a{dout->data, dout->ld}, b{raw->data, raw->ld}, o{draw->data, draw->ld};
-#define YMI_BWD_APPLY(T, GG, F, A) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, GG, F, A>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, C, coef)
+#define YMI_BWD_APPLY(T, GG, F, A) hipLaunchKernelGGL((bn_act_bwd_apply_kernel<T, GG, F, A>), dim3((unsigned)gb), dim3(256), 0, s, a, b, o, P, span, C, coef)
 #define YMI_BWD_APPLY_A(T, GG, F)                                          \
     do {                                                                   \
         if (act == YMI_ACT_SILU) YMI_BWD_APPLY(T, GG, F, YMI_ACT_SILU);      \

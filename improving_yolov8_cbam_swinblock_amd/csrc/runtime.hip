@@ -38,3 +38,10 @@ const void* ymi_zero_page() {
 
 int ew_ppt() { return 8; }     // pixels per thread the elementwise passes aim for (round-1 sweep)
 int ew_cap() { return 2048; }  // their workgroup cap
+
+// the span argument of the kernels that walk XCD-owned pixel ranges (common.h).  YMI_XCD_SHIFT=k (diagnostic knob, default 0) makes those
+// kernels work on the range of XCD (x + k) % 8 instead of their own - the anti-affine arrangement a same-box A/B measures against.
+int64_t ymi_xcd_span_arg(int64_t P) {
+    static const int shift = getenv("YMI_XCD_SHIFT") ? atoi(getenv("YMI_XCD_SHIFT")) & 7 : 0;
+    return ymi_xcd_span(P) | ((int64_t)shift << 56);
+}

@@ -170,13 +170,16 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
 #endif
     // XCD-aware order (xcd_map): workgroup ids are dealt round-robin to the 8 XCDs; all tiles of one pixel split read the
     // same dY / X rows (the nine taps are the same pixels, shifted), so a split's tiles are given to ONE XCD, back to
-    // back, and its rows are fetched into that L2 once.  Splits are dealt z = 8*i + xcd (balanced within one split).
+    // back, and its rows are fetched into that L2 once.  An XCD gets CONSECUTIVE splits, z = xcd * ceil(splits / 8) + i: its
+    // eighth of the pixel order (common.h, XCD ownership of the pixel axis) - the BatchNorm apply pass wrote those dY rows from
+    // this XCD a launch ago (round 3 dealt z = 8 i + xcd: every split's rows came from the other seven L2s).
     int bx, by, bz;
     if (a.xcd_map) {
         const int id = blockIdx.x, xcd = id & 7, seq = id >> 3, nxy = a.nx * a.ny;
         const int zi = seq / nxy, t = seq - zi * nxy;
-        bz = zi * 8 + xcd;
-        if (bz >= a.splits) return;  // padding ids leave before any barrier
+        const int spx = (a.splits + 7) >> 3;
+        bz = xcd * spx + zi;
+        if (zi >= spx || bz >= a.splits) return;  // padding ids leave before any barrier
         by = t / a.nx;
         bx = t - by * a.nx;
     } else {

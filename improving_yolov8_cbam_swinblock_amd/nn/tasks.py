@@ -138,6 +138,7 @@ class BaseModel(nn.Module):
         straight into their slice of its buffer (no copies for conv.py:683 `torch.cat`), and a layer output with several
         consumers carries an ops.GradJoin, so its gradient sum forms in a consumer's kernel instead of autograd adds."""
         y = []
+        ops.new_forward_epoch()  # (weights used twice within ONE forward are shared: their gradients are never deferred)
         self._begin_weight_arena(x)
         plan = self._graph_plan() if (self.training and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda) else None
         bufs = {}

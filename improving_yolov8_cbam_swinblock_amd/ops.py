@@ -274,14 +274,36 @@ def _adoptable(params):
     return True
 
 
+# A weight used more than once in one forward (shared weights): autograd's input buffer sums the gradients of the uses BEFORE AccumulateGrad
+# sees them, i.e. it READS them during the pass - none of them may be deferred (round-3 ADVICE).  Which weights are shared is only
+# known once the forward is over, so every weight-consuming Function counts its uses per forward "epoch" (a model forward starts a new
+# one: BaseModel._predict_once); modules called on their own never start an epoch, so a second call already counts as sharing - the
+# safe side: their gradients are complete when the Function returns.
+_use_epoch = [0]
+
+
+def new_forward_epoch():
+    _use_epoch[0] += 1
+
+
+def _note_use(*params):
+    for w in params:
+        if w is None:
+            continue
+        st = getattr(w, "_ymi_use", None)
+        if st is None or st[0] != _use_epoch[0]:
+            w._ymi_use = [_use_epoch[0], 1]
+        else:
+            st[1] += 1
+
+
 def _deferred_twice(params):
-    """True when one of these parameters already has a deferred gradient in THIS pass (a weight used twice in one graph): autograd
-    would sum the two still unfilled tensors before AccumulateGrad runs, and both slab sums would then overwrite the same `.grad`
-    instead of accumulating - the second use gets its complete gradient at once (round-3 ADVICE)."""
-    if _deferred["task"] != torch._C._current_graph_task_id():
-        return False
-    seen = _deferred["owner_ids"]
-    return any(p is not None and id(p) in seen for p in params)
+    """True when one of these parameters was used more than once in the forward this backward belongs to."""
+    for p in params:
+        st = getattr(p, "_ymi_use", None) if p is not None else None
+        if st is not None and st[1] > 1:
+            return True
+    return False
 
 
 def _in_backward():
@@ -359,7 +381,7 @@ def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias, params=()):
 # So the deferral is OPT-IN: engine.trainer.TrainStep, which zeroes gradients with set_to_none=True after every step and
 # knows its DDP schedule, enables it around its backward.  Everywhere else (plain autograd use of the modules, gradient
 # accumulation, hooks) each weight gradient is complete when its Function returns.
-_deferred = {"on": False, "records": [], "keep": [], "owners": [], "owner_ids": set(), "task": None, "table": None}
+_deferred = {"on": False, "records": [], "keep": [], "owners": [], "task": None, "table": None}
 
 
 class deferred_wgrad:
@@ -387,7 +409,6 @@ def set_wgrad_deferred(flag):
 def _flush_wgrads():
     recs, keep, owners = _deferred["records"], _deferred["keep"], _deferred["owners"]
     _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["task"] = [], [], [], None
-    _deferred["owner_ids"] = set()
     if not recs:
         return
     # Every node of the pass has run: a parameter's AccumulateGrad has either ADOPTED the returned tensor (p.grad is that
@@ -421,7 +442,6 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
         # first deferred gradient of this pass.  Records of an earlier pass whose end-of-pass callback never ran (the engine
         # drops callbacks when a backward raises) are stale: their gradient tensors are gone - discard them.
         _deferred["records"], _deferred["keep"], _deferred["owners"] = [], [], []
-        _deferred["owner_ids"] = set()
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
         _deferred["task"] = task
     dev = x.device
@@ -436,8 +456,6 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
     _deferred["records"].append(rec)
     _deferred["keep"].append((ws, x, dy))
     _deferred["owners"].append(owner)
-    if owner is not None:
-        _deferred["owner_ids"].add(id(owner))
     return dw, (db[:cout] if want_bias else None)
 
 
@@ -603,6 +621,7 @@ class _ConvBnAct(torch.autograd.Function):
         n, cp, h, w = x.shape
         ho, wo = _conv_out_hw(h, w, k, stride)
         dev = x.device
+        _note_use(weight)
         wp = pack_conv_fwd(weight, cp, dtype)
         raw = empty_nhwc(n, o, ho, wo, dtype, dev)
         out = slot.view(n, o, ho, wo, dtype) if slot is not None else empty_nhwc(n, o, ho, wo, dtype, dev)
@@ -707,6 +726,7 @@ class _ConvAffineAct(torch.autograd.Function):
         w4 = _as4d(weight)
         o, i, k, _ = w4.shape
         dev = x.device
+        _note_use(weight)
         wp = pack_conv_fwd(weight, x.shape[1], dtype)
         if x.dim() == 4:
             n, cp, h, w = x.shape
@@ -848,6 +868,7 @@ class _SwinMlp(torch.autograd.Function):
         pre = torch.empty((t, hidden), dtype=dtype, device=dev)
         post = torch.empty((t, hidden), dtype=dtype, device=dev)
         out = torch.empty((t, w2.shape[0]), dtype=dtype, device=dev)
+        _note_use(w1, w2)
         w1p = pack_conv_fwd(w1, c, dtype)
         w2p = pack_conv_fwd(w2, hidden, dtype)
         check(

@@ -91,6 +91,8 @@ def main():
     ap.add_argument("--ops", default="fwd,dgrad,wgrad")
     ap.add_argument("--shape", action="append", default=[], help="extra shape 'name,cin,cout,k,stride,H' (square map; replaces the model's list)")
     ap.add_argument("--cold", action="store_true", help="evict the caches (1 GiB fill) before every timed launch: per-launch events, as a layer meets its operands inside the step")
+    ap.add_argument("--producer", action="store_true", help="forward only: the BatchNorm affine + SiLU pass that WRITES the GEMM's input runs before every timed launch, as in "
+                    "the step (chains of pass -> GEMM; columns: the pass alone, the pair, the GEMM's share); with YMI_XCD_SHIFT=k the pass works on another XCD's eighth")
     ap.add_argument("--stamps", action="store_true", help="diagnostic build (-DYMI_STAMPS) only: print the s_memtime stamps of one workgroup's K steps")
     args = ap.parse_args()
     dt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
@@ -140,6 +142,34 @@ def main():
 
         gf = 2.0 * M * cout * cin * k * k / 1e9
         line = f"{name:28s} {M:9d} {gf:7.1f} |"
+        if args.producer:
+            if h < 0:
+                continue
+            src = ops.empty_nhwc(*x.shape, dt, dev).copy_(torch.randn(x.shape, device=dev))
+            sc = torch.ones(x.shape[1], device=dev)
+            sh = torch.zeros(x.shape[1], device=dev)
+            tsrc = _lib.as_ymi(src)
+
+            def produce():
+                _lib.check(L.ymi_scale_shift_act(ctypes.byref(tsrc), _lib.ptr(sc), _lib.ptr(sh), 1, None, ctypes.byref(tx), sp))
+
+            def chain(fns):
+                for f in fns:
+                    f()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(args.iters):
+                    for f in fns:
+                        f()
+                e1.record()
+                torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / args.iters
+
+            t_p, t_g, t_pg = chain([produce]), chain([fwd]), chain([produce, fwd])
+            print(f"{name:28s} {M:9d} | pass {t_p:7.1f}  gemm warm {t_g:7.1f}  pair {t_pg:7.1f}  gemm in chain {t_pg - t_p:7.1f} us", flush=True)
+            tot["fwd"] += (t_pg - t_p) * count
+            tot["dgrad"] += t_g * count
+            continue
         for nm, fn in (("fwd", fwd), ("dgrad", dgrad), ("wgrad", wgrad)):
             if nm not in args.ops.split(","):
                 continue

@@ -57,6 +57,27 @@ __global__ __launch_bounds__(256) void rlat_kernel(const u32x4* buf, size_t unit
     if (acc == 0x12345678u) out[blockIdx.x] = acc;
 }
 
+// the same reader through LDS-DMA (global_load_lds, 16 B per lane), as the GEMM kernels stage their operands
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+template <int DEPTH>
+__global__ __launch_bounds__(256) void rdma_kernel(const u32x4* buf, size_t units_per_chunk, int shift, unsigned* out) {
+    __shared__ u32x4 ring[DEPTH * 256];
+    const int c = chunk_of(blockIdx.x, gridDim.x, shift);
+    const u32x4* p = buf + (size_t)c * units_per_chunk;
+    const int wave = threadIdx.x >> 6;
+    unsigned acc = 0;
+    for (size_t i = threadIdx.x; i + (DEPTH - 1) * 256 < units_per_chunk; i += 256 * DEPTH) {
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) __builtin_amdgcn_global_load_lds((gptr_t)(p + i + u * 256), (lptr_t)(ring + u * 256 + wave * 64), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) acc += ring[u * 256 + threadIdx.x].x;
+        asm volatile("" : "+v"(acc));
+    }
+    if (acc == 0x12345678u) out[blockIdx.x] = acc;
+}
+
 int main() {
     const int nb = 2048;
     unsigned *out, *xcc;
@@ -190,6 +211,74 @@ int main() {
             med[form] = t[t.size() / 2];
         }
         printf("%8zu %12.2f %12.2f %12.2f %12.2f\n", mb, med[0], med[1], med[2], med[3]);
+        hipFree(buf);
+    }
+    printf("chains with the LDS-DMA reader (per pair, us):\n");
+    printf("%8s %12s %12s\n", "MB", "affine", "shifted");
+    for (size_t mb : {4, 8, 13, 26, 52}) {
+        const size_t bytes = mb << 20;
+        const int nbr = 512, K = 40;
+        const size_t upc_w = bytes / 16 / nb, upc_r = bytes / 16 / nbr;
+        u32x4* buf;
+        hipMalloc(&buf, bytes);
+        double med[2];
+        for (int form = 0; form < 2; ++form) {
+            std::vector<float> t;
+            for (int it = 0; it < 9; ++it) {
+                hipEventRecord(e0);
+                for (int k = 0; k < K; ++k) {
+                    wkernel<<<nb, 256>>>(buf, upc_w, 0, it);
+                    rdma_kernel<2><<<nbr, 256>>>(buf, upc_r, form, out);
+                }
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (it >= 2) t.push_back(ms * 1e3f / K);
+            }
+            std::sort(t.begin(), t.end());
+            med[form] = t[t.size() / 2];
+        }
+        printf("%8zu %12.2f %12.2f\n", mb, med[0], med[1]);
+        hipFree(buf);
+    }
+    printf("the same chains captured into a hipGraph and replayed (per pair, us):\n");
+    printf("%8s %12s %12s\n", "MB", "affine", "shifted");
+    hipStream_t st;
+    hipStreamCreate(&st);
+    for (size_t mb : {4, 8, 13, 26}) {
+        const size_t bytes = mb << 20;
+        const int nbr = 512, K = 40;
+        const size_t upc_w = bytes / 16 / nb, upc_r = bytes / 16 / nbr;
+        u32x4* buf;
+        hipMalloc(&buf, bytes);
+        double med[2];
+        for (int form = 0; form < 2; ++form) {
+            hipGraph_t g;
+            hipGraphExec_t ge;
+            hipStreamBeginCapture(st, hipStreamCaptureModeGlobal);
+            for (int k = 0; k < K; ++k) {
+                wkernel<<<nb, 256, 0, st>>>(buf, upc_w, 0, k);
+                rlat_kernel<2><<<nbr, 256, 0, st>>>(buf, upc_r, form, out);
+            }
+            hipStreamEndCapture(st, &g);
+            hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            std::vector<float> t;
+            for (int it = 0; it < 9; ++it) {
+                hipEventRecord(e0, st);
+                hipGraphLaunch(ge, st);
+                hipEventRecord(e1, st);
+                hipEventSynchronize(e1);
+                float ms;
+                hipEventElapsedTime(&ms, e0, e1);
+                if (it >= 2) t.push_back(ms * 1e3f / K);
+            }
+            std::sort(t.begin(), t.end());
+            med[form] = t[t.size() / 2];
+            hipGraphExecDestroy(ge);
+            hipGraphDestroy(g);
+        }
+        printf("%8zu %12.2f %12.2f\n", mb, med[0], med[1]);
         hipFree(buf);
     }
     return 0;
