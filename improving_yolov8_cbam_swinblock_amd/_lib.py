@@ -71,6 +71,11 @@ _SIGNATURES = {
         [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _TP, _vp, _vp, _vp, _sz, _vp],
     ),
     "ymi_bn_act_bwd": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
+    "ymi_conv2d_bn_silu_fwd_pair": (
+        _c_i32,
+        [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _vp, _vp, _vp, _sz, _vp],
+    ),
+    "ymi_bn_act_bwd_pair": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_data": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
     "ymi_conv2d_bwd_data_add": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp]),
     "ymi_swin_mlp_fwd": (_c_i32, [_TP, _vp, _vp, _c_i64, _vp, _vp, _TP, _TP, _TP, _TP, _vp]),

@@ -297,22 +297,36 @@ extern "C" int ymi_pack_matrix(const float* src, int64_t rows, int64_t cols, int
 // ------------------------------------------------------------------------------ BatchNorm pieces
 // 32 channels x 32 row slices per 1024-thread block (short dependent chains: this kernel is pure latency);
 // sums in double so that the cross-block reduction adds nothing to the error of the per-block f32 partials.
+// second parameter set (p2): channels >= split read / update gamma2[c - split] ... - the BatchNorms of two convolutions that ran as one
+// (Detect's sibling branches, head.py:71-72); p2.gamma == nullptr: one set
+struct BnParams2 {
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    int split;
+};
 __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ part, int blocks, double count, int C,
                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
                                                            float* __restrict__ rmean, float* __restrict__ rvar, float momentum, float eps,
                                                            float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ smean,
-                                                           float* __restrict__ sinv) {
+                                                           float* __restrict__ sinv, BnParams2 p2) {
     __shared__ double red[2][32][33];
     const int cl = threadIdx.x & 31, slice = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
+    int pc = c;  // index into this channel's parameter arrays
+    if (p2.split > 0 && c >= p2.split) {
+        gamma = p2.gamma; beta = p2.beta; rmean = p2.rmean; rvar = p2.rvar;
+        pc = c - p2.split;
+    }
     double s1 = 0.0, s2 = 0.0;
     // parameters and running statistics are fetched first, beside the partials (a chain of load latencies otherwise)
     float g_ = 1.0f, b_ = 0.0f, rm_ = 0.f, rv_ = 0.f;
     if (slice == 0 && c < C) {
-        if (gamma) g_ = gamma[c];
-        if (beta) b_ = beta[c];
-        if (rmean) rm_ = rmean[c];
-        if (rvar) rv_ = rvar[c];
+        if (gamma) g_ = gamma[pc];
+        if (beta) b_ = beta[pc];
+        if (rmean) rm_ = rmean[pc];
+        if (rvar) rv_ = rvar[pc];
     }
     if (c < C) {
         // four independent chains per sum: the loads of a trip are all in flight before the first add
@@ -356,10 +370,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
         shift[c] = b - (float)mean * sc;
         if (smean) smean[c] = (float)mean;
         if (sinv) sinv[c] = inv;
-        if (rmean) rmean[c] = (1.0f - momentum) * rm_ + momentum * (float)mean;
+        if (rmean) rmean[pc] = (1.0f - momentum) * rm_ + momentum * (float)mean;
         if (rvar) {
             const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-            rvar[c] = (1.0f - momentum) * rv_ + momentum * (float)unb;
+            rvar[pc] = (1.0f - momentum) * rv_ + momentum * (float)unb;
         }
     }
 }
@@ -399,9 +413,17 @@ __global__ __launch_bounds__(256) void stat_rows_reduce_kernel(const float* __re
 constexpr int BN_STAGE_ROWS = 64;
 
 // `part` may be overwritten beyond row `blocks` (callers size it with ymi_conv2d_stat_blocks + BN_STAGE_ROWS rows).
+static int bn_finalize_impl(const float* part, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
+                            float* rmean, float* rvar, float momentum, float eps, float* scale, float* shift, float* smean,
+                            float* sinv, BnParams2 p2, void* stream);
 extern "C" int ymi_bn_finalize(const float* part, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
                                float* rmean, float* rvar, float momentum, float eps, float* scale, float* shift, float* smean,
                                float* sinv, void* stream) {
+    return bn_finalize_impl(part, blocks, count, c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv, BnParams2{nullptr, nullptr, nullptr, nullptr, 0}, stream);
+}
+static int bn_finalize_impl(const float* part, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
+                            float* rmean, float* rvar, float momentum, float eps, float* scale, float* shift, float* smean,
+                            float* sinv, BnParams2 p2, void* stream) {
     YMI_CHECK_ARG(part && scale && shift && blocks > 0 && count > 0 && c > 0, "bn_finalize: args");
     const float* src = part;
     int rows = (int)blocks;
@@ -413,7 +435,7 @@ extern "C" int ymi_bn_finalize(const float* part, int64_t blocks, int64_t count,
         rows = BN_STAGE_ROWS;
     }
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)((c + 31) / 32)), dim3(1024), 0, (hipStream_t)stream, src, rows,
-                       (double)count, (int)c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv);
+                       (double)count, (int)c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv, p2);
     YMI_CHECK_LAUNCH("bn_finalize");
     return YMI_OK;
 }
@@ -463,6 +485,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const 
     const int64_t P = xr.hi;
     const int g = threadIdx.x % groups;
     const int rows_per_block = 256 / groups;
+    if ((int)threadIdx.x >= rows_per_block * groups) return;  // group counts that do not divide 256 (192 channels: 48 groups, 5 rows, 16 idle threads); no barriers below
     float sc[4], sh[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -548,7 +571,7 @@ extern "C" int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, co
     TV r = residual ? tv(residual) : TV{nullptr, 0, 0, 0, 0, 0};
     dim3 g = ew_grid(total), b(256);
     hipStream_t s = (hipStream_t)stream;
-    if (vec && raw->c / 4 <= 256 && 256 % (raw->c / 4) == 0) {
+    if (vec && raw->c / 4 <= 256) {
         if (raw->dtype == YMI_BF16) launch_ssa_fixed<bf16_t>(raw, scale, shift, act, r, out, s);
         else launch_ssa_fixed<float>(raw, scale, shift, act, r, out, s);
         YMI_CHECK_LAUNCH("scale_shift_act");
@@ -566,10 +589,35 @@ extern "C" int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, co
 }
 
 // Conv + train-mode BN + activation: three launches, one C call.
+static int conv_bn_act_fwd_impl(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var, BnParams2 p2, float momentum,
+                                float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
+                                float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int ymi_conv2d_bn_silu_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
                                       const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
                                       float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
                                       float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream) {
+    return conv_bn_act_fwd_impl(x, w_packed, cout, kh, kw, stride, gamma, beta, running_mean, running_var, BnParams2{nullptr, nullptr, nullptr, nullptr, 0}, momentum,
+                                eps, act, residual, raw, out, save_mean, save_invstd, workspace, workspace_bytes, stream);
+}
+// Two convolutions of the SAME input as one (their packed weights lie back to back: output channels [0, split) are the first's,
+// [split, cout) the second's), each with its own BatchNorm parameters and running statistics.  BatchNorm is per channel, so this is
+// exactly the two separate Conv blocks; `raw` / `out` hold both results side by side.  Reference: Detect.forward reads x[i] with
+// cv2[i] and cv3[i] (nn/modules/head.py:71-72).
+extern "C" int ymi_conv2d_bn_silu_fwd_pair(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t split, int64_t kh, int64_t kw, int64_t stride,
+                                           const float* gamma, const float* beta, float* running_mean, float* running_var, const float* gamma2,
+                                           const float* beta2, float* running_mean2, float* running_var2, float momentum, float eps, int32_t act,
+                                           const ymi_tensor* raw, const ymi_tensor* out, float* save_mean, float* save_invstd, void* workspace,
+                                           size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(split > 0 && split < cout && split % 4 == 0 && gamma2 && beta2, "conv2d_bn_silu_fwd_pair: split");
+    return conv_bn_act_fwd_impl(x, w_packed, cout, kh, kw, stride, gamma, beta, running_mean, running_var,
+                                BnParams2{gamma2, beta2, running_mean2, running_var2, (int)split}, momentum, eps, act, nullptr, raw, out, save_mean, save_invstd,
+                                workspace, workspace_bytes, stream);
+}
+static int conv_bn_act_fwd_impl(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var, BnParams2 p2, float momentum,
+                                float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
+                                float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(raw) && ymi_tensor_ok(out) && workspace, "conv2d_bn_silu_fwd: bad tensor");
     const int64_t m = ymi_pixels(raw);
     const int64_t maxblk = ymi_conv2d_stat_blocks(m, cout);
@@ -584,7 +632,7 @@ extern "C" int ymi_conv2d_bn_silu_fwd(const ymi_tensor* x, const void* w_packed,
     int64_t blocks = 0;
     int rc = ymi_conv2d_fwd(x, w_packed, cout, kh, kw, stride, nullptr, nullptr, YMI_ACT_NONE, nullptr, raw, part, &blocks, stream);
     if (rc) return rc;
-    rc = ymi_bn_finalize(part, blocks, m, cout, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, stream);
+    rc = bn_finalize_impl(part, blocks, m, cout, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, p2, stream);
     if (rc) return rc;
     return ymi_scale_shift_act(raw, scale, shift, act, residual, out, stream);
 }

@@ -7,7 +7,10 @@ struct PackDesc {  // mirrors ymi_pack_desc
     const float* src;
     void* dst_fwd;
     void* dst_dgrad;
-    int32_t o, i, kh, kw, ipad, opad, stride, pad_;
+    int32_t o, i, kh, kw, ipad, opad, stride;
+    int32_t ostride;  // row length of the data-gradient operand (0: opad).  Larger than opad when several weights share one operand:
+    int32_t o_off;    // ... this weight's first column in it (Detect's sibling convolutions, head.py:71-72, run as ONE convolution)
+    int32_t pad_;
 };
 
 // Both operands are re-orderings of the OIHW source ([O][I][taps]): forward [O][tap][Ipad], data gradient [I][tap in class][Opad] - the
@@ -31,6 +34,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
     const PackDesc d = descs[lo];
     const uint32_t blk = (uint32_t)((int)blockIdx.x - block_start[lo]);
     const uint32_t taps = (uint32_t)(d.kh * d.kw), I = (uint32_t)d.i, O = (uint32_t)d.o;
+    if (taps > 9) return;  // the LDS tile holds nine taps: a larger kernel would write past it (the host-side callers only build k <= 3; workgroup-uniform)
     const uint32_t omax = d.dst_dgrad && (uint32_t)d.opad > O ? (uint32_t)d.opad : O;  // (the launcher's tile count uses the padded input extent likewise)
     const uint32_t tiles_o = (omax + PK_T - 1) / PK_T;
     const uint32_t o0 = (blk % tiles_o) * PK_T, c0 = (blk / tiles_o) * PK_T;
@@ -55,7 +59,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
         const int pad = d.kh / 2, smask = d.stride - 1;  // stride 1 or 2: (v % stride == 0) <=> ((v & smask) == 0)
         const int nclass = d.stride == 1 ? 1 : 4;
         const uint32_t o = o0 + lane32;
-        uint64_t class_off = 0;
+        const uint32_t ostride = d.ostride ? (uint32_t)d.ostride : (uint32_t)d.opad;
+        uint64_t class_off = (uint64_t)d.o_off;
         for (int cls = 0; cls < nclass; ++cls) {
             const int ph = d.stride == 1 ? 0 : cls >> 1, pw = d.stride == 1 ? 0 : cls & 1;
             int nt = 0;
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
                     if (((ph + pad - a) & smask) == 0 && ((pw + pad - b) & smask) == 0) {
                         if (o < (uint32_t)d.opad)
                             for (uint32_t cl = grp; cl < PK_T && c0 + cl < I; cl += 256 / PK_T)
-                                dst[class_off + ((uint64_t)(c0 + cl) * nt + tq) * d.opad + o] = tile[((a * d.kw + b) * PK_T + cl) * (PK_T + 2) + lane32];
+                                dst[class_off + ((uint64_t)(c0 + cl) * nt + tq) * ostride + o] = tile[((a * d.kw + b) * PK_T + cl) * (PK_T + 2) + lane32];
                         ++tq;
                     }
-            class_off += (uint64_t)I * nt * d.opad;
+            class_off += (uint64_t)I * nt * ostride;
         }
     }
 }
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackDesc* __restr
 extern "C" int ymi_pack_conv_weights_batch(const void* descs_device, const int32_t* block_start_device, int32_t count, int32_t total_blocks,
                                            int32_t dtype, void* stream) {
     YMI_CHECK_ARG(descs_device && block_start_device && count > 0 && total_blocks > 0, "pack_conv_weights_batch: args");  // (kh * kw <= 9: the LDS tile)
-    static_assert(sizeof(PackDesc) == 56, "ymi_pack_desc layout");
+    static_assert(sizeof(PackDesc) == 64 && sizeof(PackDesc) == sizeof(ymi_pack_desc), "ymi_pack_desc layout");
     if (dtype == YMI_BF16)
         hipLaunchKernelGGL(pack_batch_kernel<bf16_t>, dim3((unsigned)total_blocks), dim3(256), 0, (hipStream_t)stream,
                            reinterpret_cast<const PackDesc*>(descs_device), block_start_device, (int)count);

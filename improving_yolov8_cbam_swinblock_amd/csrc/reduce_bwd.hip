@@ -15,9 +15,16 @@ struct RV {
 // FN: 0 colsum(a)            -> s0 = sum a
 //     1 bn-act backward      -> dz = a * act'(z), z = (b-mean)*inv*gamma+beta ; s0 = sum dz, s1 = sum dz*xhat
 //     2 layernorm param grads-> s0 = sum a (dbeta), s1 = sum a * (b - mean_row)*rstd_row (dgamma); mean/rstd per ROW
+// gamma / beta of the channels >= split come from a second pair of arrays (two BatchNorms behind one convolution: Detect's sibling
+// branches run as one, head.py:71-72); split == 0: one pair
+struct GammaBeta2 {
+    const float* gamma;
+    const float* beta;
+    int split;
+};
 template <typename T, int FN, int ACT>
 __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part) {
+                                   const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part, GammaBeta2 g2) {
     extern __shared__ float red[];  // [rows][TG][8]
     const int rows = 256 / TG;
     const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
@@ -37,8 +44,12 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int c = c0 + tx * 4 + r;
-            g[r] = (FN == 1 && gamma) ? gamma[c] : 1.0f;
-            be[r] = (FN == 1 && beta) ? beta[c] : 0.0f;
+            const bool second = g2.split > 0 && c >= g2.split;
+            const float* gp = second ? g2.gamma : gamma;
+            const float* bp = second ? g2.beta : beta;
+            const int pc = second ? c - g2.split : c;
+            g[r] = (FN == 1 && gp) ? gp[pc] : 1.0f;
+            be[r] = (FN == 1 && bp) ? bp[pc] : 0.0f;
             mu[r] = (FN == 1) ? mean[c] : 0.0f;
             iv[r] = (FN == 1) ? inv[c] : 1.0f;
         }
@@ -139,6 +150,7 @@ struct BnCoefArgs {
     const float* inv;
     float inv_count;
     float* coef;  // [5][C] or nullptr
+    GammaBeta2 g2;
 };
 
 __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1,
@@ -151,8 +163,12 @@ __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __
     // latencies: behind the barrier they were a round trip of their own)
     float ga = 1.0f, be = 0.0f, p_inv = 0.f, p_mean = 0.f;
     if (slice == 0 && c < C && bn.coef) {
-        ga = bn.gamma ? bn.gamma[c] : 1.0f;
-        be = bn.beta ? bn.beta[c] : 0.0f;
+        const bool second = bn.g2.split > 0 && c >= bn.g2.split;
+        const float* gp = second ? bn.g2.gamma : bn.gamma;
+        const float* bp = second ? bn.g2.beta : bn.beta;
+        const int pc = second ? c - bn.g2.split : c;
+        ga = gp ? gp[pc] : 1.0f;
+        be = bp ? bp[pc] : 0.0f;
         p_inv = bn.inv[c];
         p_mean = bn.mean[c];
     }
@@ -223,7 +239,8 @@ static int reduce_blocks(int64_t P, int C) {
 
 template <int FN>
 static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const float* gamma, const float* beta, const float* mean,
-                              const float* inv, int act, float* part, int* blocks_out, hipStream_t stream, const char* what) {
+                              const float* inv, int act, float* part, int* blocks_out, hipStream_t stream, const char* what,
+                              GammaBeta2 g2 = GammaBeta2{nullptr, nullptr, 0}) {
     const int64_t P = ymi_pixels(a);
     const int C = (int)a->c;
     YMI_CHECK_ARG(C % 4 == 0 && a->ld % 4 == 0 && (!b || (b->ld % 4 == 0)), "%s: channels must be a multiple of 4", what);
@@ -232,7 +249,7 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
     const int blocks = reduce_blocks(P, C);
     const size_t lds = (size_t)256 * 8 * sizeof(float);
     RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
-#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, ymi_xcd_span_arg(P), C, TG, gamma, beta, mean, inv, part)
+#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, ymi_xcd_span_arg(P), C, TG, gamma, beta, mean, inv, part, g2)
 #define YMI_CR_T(T)                                                      \
     do {                                                                 \
         if (FN != 1 || act == YMI_ACT_NONE) YMI_CR(T, YMI_ACT_NONE);     \
@@ -249,7 +266,7 @@ static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const fl
 }
 
 int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, float* out1, hipStream_t stream) {
-    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, blocks, C, out0, out1, BnCoefArgs{});
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, blocks, C, out0, out1, BnCoefArgs{});  // (value-initialised: no coefficients)
     YMI_CHECK_LAUNCH("chan_reduce_final");
     return YMI_OK;
 }
@@ -294,6 +311,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
     T* op = reinterpret_cast<T*>(const_cast<void*>(draw.p));
     if constexpr (FIXED) {
         const int g = threadIdx.x % groups, rows = 256 / groups;
+        if ((int)threadIdx.x >= rows * groups) return;  // group counts that do not divide 256 (192 channels); no barriers in this kernel
         float a0[G], a1[G], c0[G], c1[G], c2[G];
 #pragma unroll
         for (int r = 0; r < G; ++r) {
@@ -396,7 +414,7 @@ static int launch_bn_apply(const ymi_tensor* dout, const ymi_tensor* raw, const 
     const bool bf = dout->dtype == YMI_BF16;
     const int G = 4;  // 8-byte (bf16) / 16-byte (f32) channel groups (16-byte groups for bf16 measured equal in round 2: removed)
     const int groups = C / G;
-    const bool fixed = groups <= 256 && 256 % groups == 0;
+    const bool fixed = groups <= 256;
     const int64_t total = P * groups;
     YMI_CHECK_ARG(total < (1ll << 31), "bn_act_bwd: tensor too large for 32-bit indexing");
     int64_t gb;
@@ -432,9 +450,24 @@ static int launch_bn_apply(const ymi_tensor* dout, const ymi_tensor* raw, const 
     return YMI_OK;
 }
 
+static int bn_act_bwd_impl(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
+                           const float* save_invstd, const float* beta, GammaBeta2 g2, int32_t act, const ymi_tensor* draw, float* dgamma,
+                           float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
                               const float* save_invstd, const float* beta, int32_t act, const ymi_tensor* draw, float* dgamma,
                               float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    return bn_act_bwd_impl(dout, raw, gamma, save_mean, save_invstd, beta, GammaBeta2{nullptr, nullptr, 0}, act, draw, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+// backward of ymi_conv2d_bn_silu_fwd_pair's BatchNorm + activation: channels >= split use gamma2 / beta2; dgamma / dbeta hold all channels
+extern "C" int ymi_bn_act_bwd_pair(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* beta, const float* gamma2,
+                                   const float* beta2, int64_t split, const float* save_mean, const float* save_invstd, int32_t act,
+                                   const ymi_tensor* draw, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
+    YMI_CHECK_ARG(dout && split > 0 && split < dout->c && split % 4 == 0 && gamma2 && beta2, "bn_act_bwd_pair: split");
+    return bn_act_bwd_impl(dout, raw, gamma, save_mean, save_invstd, beta, GammaBeta2{gamma2, beta2, (int)split}, act, draw, dgamma, dbeta, workspace, workspace_bytes, stream);
+}
+static int bn_act_bwd_impl(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
+                           const float* save_invstd, const float* beta, GammaBeta2 g2, int32_t act, const ymi_tensor* draw, float* dgamma,
+                           float* dbeta, void* workspace, size_t workspace_bytes, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(dout) && ymi_tensor_ok(raw) && ymi_tensor_ok(draw) && ymi_same_shape(dout, raw) && ymi_same_shape(dout, draw),
                   "bn_act_bwd: shapes");
     YMI_CHECK_ARG(dout->dtype == raw->dtype && raw->dtype == draw->dtype, "bn_act_bwd: dtypes");
@@ -450,12 +483,12 @@ extern "C" int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, con
     }
     hipStream_t s = (hipStream_t)stream;
     int blocks = 0;
-    int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)");
+    int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)", g2);
     if (rc) return rc;
     float* coef = (float*)workspace + (size_t)blocks * 2 * C;
     // dbeta = sum dz, dgamma = sum dz*xhat, and the apply pass's coefficients
     hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)workspace, blocks, C, dbeta, dgamma,
-                       BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef});
+                       BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef, g2});
     YMI_CHECK_LAUNCH("bn_act_bwd(final)");
     return launch_bn_apply(dout, raw, draw, act, coef, s);
 }

@@ -1,5 +1,6 @@
 """Detect head (reference: ultralytics/nn/modules/head.py:23-183), legacy (v8) class branch."""
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -73,13 +74,37 @@ class Detect(nn.Module):
             h = m(h)
         return h
 
+    @property
+    def pair_ok(self):
+        """the first convolutions of the two branches of a level read the same input (reference head.py:71-72): in training they run as ONE
+        convolution with c2 + c3 output channels (ops.conv_bn_act_pair).  A static property of the module (the model graph counts Detect as
+        ONE consumer of each input when it holds): both are unfused Conv blocks with SiLU and widths in whole 16-byte bf16 chunks."""
+        a, b = self.cv2[0][0], self.cv3[0][0]
+        if os.environ.get("YMI_DETECT_PAIR", "1") == "0":  # diagnostic knob: the two branches as separate convolutions (same-box A/B)
+            return False
+        return (hasattr(a, "bn") and hasattr(b, "bn") and isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU)
+                and a.conv.out_channels % 8 == 0 and b.conv.out_channels % 8 == 0 and a.conv.kernel_size == b.conv.kernel_size)
+
+    def _level(self, i, xi):
+        """(box map, class map) of level i from the internal tensor xi."""
+        a, b = self.cv2[i], self.cv3[i]
+        if self.training and torch.is_grad_enabled() and self.pair_ok:
+            h = ops.conv_bn_act_pair(xi, a[0].conv, a[0].bn, b[0].conv, b[0].bn)
+            ha, hb = ops.chan_split2(h, a[0].conv.out_channels)
+            for m in a[1:]:
+                ha = m(ha)
+            for m in b[1:]:
+                hb = m(hb)
+            return ha, hb
+        return self._branch(a, xi), self._branch(b, xi)
+
     def forward(self, x):
         x = list(x)
         box, cls = [], []
         for i in range(self.nl):
-            xi = ops.to_internal(x[i])
-            box.append(self._branch(self.cv2[i], xi))
-            cls.append(self._branch(self.cv3[i], xi))
+            bi, ci = self._level(i, ops.to_internal(x[i]))
+            box.append(bi)
+            cls.append(ci)
             x[i] = ops.concat([box[i], cls[i]])
         if self.training:
             return x
@@ -92,9 +117,9 @@ class Detect(nn.Module):
         -> (box list [B, 64, H, W], cls list [B, nc, H, W]).  Used by DetectionModel.loss."""
         box, cls = [], []
         for i in range(self.nl):
-            xi = ops.to_internal(x[i])
-            box.append(self._branch(self.cv2[i], xi))
-            cls.append(self._branch(self.cv3[i], xi))
+            bi, ci = self._level(i, ops.to_internal(x[i]))
+            box.append(bi)
+            cls.append(ci)
         return box, cls
 
     def _inference(self, box, cls=None):

@@ -187,7 +187,8 @@ class BaseModel(nn.Module):
             for j in srcs[m.i]:
                 if j < 0:
                     continue
-                consumers[j] = consumers.get(j, 0) + (2 if isinstance(m, Detect) else 1)  # Detect reads each input with two branches
+                # Detect reads each input with two branches - as ONE convolution when its sibling first convolutions run as a pair
+                consumers[j] = consumers.get(j, 0) + ((1 if m.pair_ok else 2) if isinstance(m, Detect) else 1)
                 ok[j] = ok.get(j, True) and isinstance(m, join_ok)
             if isinstance(m, Concat):
                 off, total = 0, sum(outs[j][0] for j in srcs[m.i])

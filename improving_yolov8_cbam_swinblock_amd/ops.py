@@ -109,7 +109,7 @@ def to_nchw_float(x):
 class _PackDesc(ctypes.Structure):
     _fields_ = [("src", ctypes.c_void_p), ("dst_fwd", ctypes.c_void_p), ("dst_dgrad", ctypes.c_void_p), ("o", ctypes.c_int32),
                 ("i", ctypes.c_int32), ("kh", ctypes.c_int32), ("kw", ctypes.c_int32), ("ipad", ctypes.c_int32), ("opad", ctypes.c_int32),
-                ("stride", ctypes.c_int32), ("_pad", ctypes.c_int32)]
+                ("stride", ctypes.c_int32), ("ostride", ctypes.c_int32), ("o_off", ctypes.c_int32), ("_pad", ctypes.c_int32)]
 
 
 class WeightArena:
@@ -118,21 +118,28 @@ class WeightArena:
     Life cycle: while `recording`, the per-call packers below note (weight, padding, stride) of every use during one
     full forward+backward; `build()` then allocates one arena and a device descriptor table; afterwards `pack()`
     (called at the start of each training forward) refreshes every operand with a single kernel and the per-call
-    packers return views of the arena.  A use that was not recorded simply falls back to its own pack launch."""
+    packers return views of the arena.  A use that was not recorded simply falls back to its own pack launch.
+
+    A spec holds ONE weight, or a PAIR of weights of the same input that run as one convolution (Detect's sibling branches,
+    reference head.py:71-72): the pair's forward operands lie back to back ([oA + oB][tap][ipad]) and its data-gradient operand has
+    the two column ranges side by side ([i][tap][oA + oB], ymi_pack_desc.ostride / o_off)."""
 
     def __init__(self):
-        self.specs = {}      # id(weight) -> dict(weight, o, i, k, ipad, opad, stride)
+        self.specs = {}      # id(weight) | (id(wA), id(wB)) -> dict(weights, o (tuple), i, k, ipad, opad, stride)
         self.dtype = None
         self.built = False
         self.fresh = False   # operands correspond to the current weight values
         self.views = {}
 
-    def note(self, weight, dtype, ipad=None, opad=None, stride=1):
+    def note(self, weight, dtype, ipad=None, opad=None, stride=1, pair=None):
+        """pair: the second weight when (weight, pair) run as one convolution (opad is then the two real widths' sum)."""
         if self.built:
             return
-        w4 = _as4d(weight)
-        o, i, k, _ = w4.shape
-        sp = self.specs.setdefault(id(weight), dict(weight=weight, o=o, i=i, k=k, ipad=None, opad=None, stride=1))
+        ws = (weight,) if pair is None else (weight, pair)
+        w4 = [_as4d(w) for w in ws]
+        i, k = w4[0].shape[1], w4[0].shape[2]
+        key = id(weight) if pair is None else (id(weight), id(pair))
+        sp = self.specs.setdefault(key, dict(weights=ws, o=tuple(w.shape[0] for w in w4), i=i, k=k, ipad=None, opad=None, stride=1))
         if ipad is not None:
             sp["ipad"] = ipad
         if opad is not None:
@@ -142,32 +149,46 @@ class WeightArena:
     def build(self):
         if not self.specs:
             return
-        dev = next(iter(self.specs.values()))["weight"].device
+        dev = next(iter(self.specs.values()))["weights"][0].device
         es = 2 if self.dtype == torch.bfloat16 else 4
         total, plan = 0, []
         for key, sp in self.specs.items():
-            nf = sp["o"] * sp["k"] ** 2 * sp["ipad"] if sp["ipad"] else 0
+            if sp["k"] > 3:
+                raise RuntimeError("weight arena: kernels larger than 3x3 are not packed in one launch (the pack kernel's LDS tile holds nine taps)")
+            osum = sum(sp["o"])
+            nf = osum * sp["k"] ** 2 * sp["ipad"] if sp["ipad"] else 0
             nd = sp["i"] * sp["k"] ** 2 * sp["opad"] if sp["opad"] else 0
             offf, total = total, total + round_up(nf, 8)
             offd, total = total, total + round_up(nd, 8)
             plan.append((key, sp, nf, nd, offf, offd))
         self.arena = torch.empty(total, dtype=self.dtype, device=dev)
-        descs = (_PackDesc * len(plan))()
+        ndesc = sum(len(sp["weights"]) for _, sp, *_ in plan)
+        descs = (_PackDesc * ndesc)()
         starts = [0]
         base = self.arena.data_ptr()
-        for n, (key, sp, nf, nd, offf, offd) in enumerate(plan):
-            w = sp["weight"]
-            descs[n] = _PackDesc(w.data_ptr(), base + offf * es if nf else None, base + offd * es if nd else None, sp["o"], sp["i"], sp["k"],
-                                 sp["k"], sp["ipad"] or 0, sp["opad"] or 0, sp["stride"], 0)
-            # workgroups: one per 32 x 32 tile of (output, input) channels, padded extents included (include/ymi.h)
-            wgs = ((max(sp["o"], sp["opad"] if nd else 0) + 31) // 32) * ((max(sp["i"], sp["ipad"] if nf else 0) + 31) // 32)
-            starts.append(starts[-1] + wgs)
+        self.params = []
+        n = 0
+        for key, sp, nf, nd, offf, offd in plan:
+            pair = len(sp["weights"]) == 2
+            k2 = sp["k"] ** 2
+            o_off = 0
+            for w, o in zip(sp["weights"], sp["o"]):
+                # (a pair: forward rows of the second weight follow the first's; in the data-gradient operand each weight owns the
+                # columns [o_off, o_off + o) of rows that are opad = oA + oB long - the widths are whole 16-byte chunks, no padding between)
+                opad_w = (o if pair else sp["opad"]) if nd else 0
+                descs[n] = _PackDesc(w.data_ptr(), base + (offf + o_off * k2 * (sp["ipad"] or 0)) * es if nf else None, base + offd * es if nd else None,
+                                     o, sp["i"], sp["k"], sp["k"], sp["ipad"] or 0, opad_w, sp["stride"], (sp["opad"] if (pair and nd) else 0), o_off if pair else 0, 0)
+                # workgroups: one per 32 x 32 tile of (output, input) channels, padded extents included (include/ymi.h)
+                wgs = ((max(o, opad_w) + 31) // 32) * ((max(sp["i"], sp["ipad"] if nf else 0) + 31) // 32)
+                starts.append(starts[-1] + wgs)
+                self.params.append(w)
+                o_off += o
+                n += 1
             self.views[key] = (self.arena[offf : offf + nf] if nf else None, self.arena[offd : offd + nd] if nd else None, sp["ipad"], sp["opad"], sp["stride"])
         raw = bytes(descs)
         self.descs = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
         self.starts = torch.tensor(starts, dtype=torch.int32).to(dev)
-        self.count, self.blocks = len(plan), starts[-1]
-        self.params = [sp["weight"] for _, sp, *_ in plan]
+        self.count, self.blocks = ndesc, starts[-1]
         self.ptrs = [w.data_ptr() for w in self.params]  # the descriptor table holds these raw addresses
         self.built = True
 
@@ -184,21 +205,21 @@ class WeightArena:
         self.versions = {id(w): w._version for w in self.params}
         self.fresh = True
 
-    def _view(self, weight, dtype):
+    def _view(self, weight, dtype, pair=None):
         if not (self.built and self.fresh and dtype == self.dtype):
             return None
-        key = id(weight)
+        key = id(weight) if pair is None else (id(weight), id(pair))
         v = self.views.get(key)
-        if v is None or self.versions.get(key) != weight._version:
+        if v is None or any(self.versions.get(id(w)) != w._version for w in ((weight,) if pair is None else (weight, pair))):
             return None
         return v
 
-    def lookup_fwd(self, weight, ipad, dtype):
-        v = self._view(weight, dtype)
+    def lookup_fwd(self, weight, ipad, dtype, pair=None):
+        v = self._view(weight, dtype, pair)
         return v[0] if v is not None and v[0] is not None and v[2] == ipad else None
 
-    def lookup_dgrad(self, weight, opad, stride, dtype):
-        v = self._view(weight, dtype)
+    def lookup_dgrad(self, weight, opad, stride, dtype, pair=None):
+        v = self._view(weight, dtype, pair)
         return v[1] if v is not None and v[1] is not None and v[3] == opad and v[4] == stride else None
 
 
@@ -236,6 +257,35 @@ def pack_conv_dgrad(weight, cout_pad, stride, dtype):
     return buf
 
 
+def pack_conv_fwd_pair(wa, wb, cin_pad, dtype):
+    """forward operand of two convolutions of one input run as ONE: [oA + oB][kh][kw][cin_pad] (a view of the arena once it is built)."""
+    if _arena is not None:
+        hit = _arena.lookup_fwd(wa, cin_pad, dtype, pair=wb)
+        if hit is not None:
+            return hit
+        _arena.note(wa, dtype, ipad=cin_pad, pair=wb)
+    w = torch.cat([wa.detach(), wb.detach()], 0)  # (only until the arena exists - the warm-up steps - and in stand-alone use: never inside a captured graph)
+    o, i, kh, kw = w.shape
+    buf = torch.empty(o * kh * kw * cin_pad, dtype=dtype, device=w.device)
+    check(L().ymi_pack_conv_weight_fwd(ptr(w), o, i, kh, kw, cin_pad, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_fwd")
+    return buf
+
+
+def pack_conv_dgrad_pair(wa, wb, stride, dtype):
+    """data-gradient operand of the pair: [i][tap][oA + oB] per stride-parity class."""
+    otot = wa.shape[0] + wb.shape[0]
+    if _arena is not None:
+        hit = _arena.lookup_dgrad(wa, otot, stride, dtype, pair=wb)
+        if hit is not None:
+            return hit
+        _arena.note(wa, dtype, opad=otot, stride=stride, pair=wb)
+    w = torch.cat([wa.detach(), wb.detach()], 0)
+    o, i, kh, kw = w.shape
+    buf = torch.empty(o * i * kh * kw, dtype=dtype, device=w.device)
+    check(L().ymi_pack_conv_weight_dgrad_ex(ptr(w), o, o, i, kh, kw, stride, ymi_dtype(dtype), ptr(buf), stream_ptr()), "pack_conv_weight_dgrad")
+    return buf
+
+
 def _as4d(w):
     return w if w.dim() == 4 else w.view(w.shape[0], w.shape[1], 1, 1)
 
@@ -245,10 +295,12 @@ def _conv_out_hw(h, w, k, s):
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
-def _wgrad(x, dy, cout, cin, k, stride, want_bias, params=()):
-    """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None).  params: the parameters these gradients belong to."""
+def _wgrad(x, dy, cout, cin, k, stride, want_bias, params=(), pair_rows=None):
+    """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None).  params: the parameters these gradients belong to.
+    pair_rows: params are TWO weights whose gradients are the row ranges [0, pair_rows) and [pair_rows, cout) of dw (_ConvBnActPair)."""
     if _deferred["on"] and _in_backward() and _adoptable(params) and not _deferred_twice(params):
-        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, params[0] if params else None)
+        owner = (params[0], params[1], int(pair_rows)) if pair_rows else (params[0] if params else None)
+        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner)
     dev = x.device
     dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
     ty, tx = as_ymi(dy), as_ymi(x)
@@ -356,14 +408,14 @@ def join_side_stream():
         _async["keep"].clear()
 
 
-def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias, params=()):
+def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias, params=(), pair_rows=None):
     if not _async["on"]:
-        return _wgrad(x, dy, cout, cin, k, stride, want_bias, params)
+        return _wgrad(x, dy, cout, cin, k, stride, want_bias, params, pair_rows)
     cur = torch.cuda.current_stream()
     side = _side_stream(x.device)
     side.wait_stream(cur)
     with torch.cuda.stream(side):
-        out = _wgrad(x, dy, cout, cin, k, stride, want_bias, params)
+        out = _wgrad(x, dy, cout, cin, k, stride, want_bias, params, pair_rows)
     _async["keep"].append((x, dy))
     _async["pending"] = True
     return out
@@ -416,6 +468,15 @@ def _flush_wgrads():
     # AccumulateGrad clone it) or, if the gradient layout contract failed, stored a clone of the still unfilled tensor and
     # dropped the original.  In the second case the sum is written straight into p.grad instead of into freed memory.
     for rec, owner in zip(recs, owners):
+        if isinstance(owner, tuple):
+            # two parameters share one [oA + oB, ...] result as its two row ranges (_ConvBnActPair): both must have ADOPTED their view -
+            # a cloned half cannot be redirected (the sum is one write of the whole tensor), so that case is refused loudly
+            pa, pb, rows = owner
+            per_row = rec.cin_real * rec.ntaps * 4
+            ok = (pa.grad is not None and pb.grad is not None and pa.grad.data_ptr() == rec.dw and pb.grad.data_ptr() == rec.dw + rows * per_row)
+            if not ok:
+                raise RuntimeError("deferred weight gradient of a convolution pair: AccumulateGrad did not adopt both halves of the result")
+            continue
         g = owner.grad if owner is not None else None
         if g is not None and g.data_ptr() != rec.dw and g.dtype == torch.float32 and g.is_contiguous():
             rec.dw = g.data_ptr()
@@ -470,10 +531,12 @@ class GradJoin:
     Reference sites: Bottleneck shortcut (block.py:488), the two Detect branches (head.py:72), neck skip connections
     (yolov8.yaml:760-773), SwinBlock residuals (swin_block.py:52-53), C2f chunk / concat (block.py:302-304)."""
 
-    __slots__ = ("n", "seen", "pending", "out")
+    __slots__ = ("n", "seen", "pending", "out", "dst")
 
     def __init__(self, n):
         self.n, self.seen, self.pending = int(n), 0, []
+        # optional: where the total should be WRITTEN (a _GradSlot: a channel slice of a wider gradient buffer; see _ChanSplit2)
+        self.dst = None
         # optional: a buffer that already holds one more contribution (set during backward by the producer of that contribution);
         # the last-arriving data gradient then adds it as an addend AND writes the total there (C2f's chunk: see _C2fSplit)
         self.out = None
@@ -536,14 +599,18 @@ def _prep_adds(adds, dtype, like4d):
     return out
 
 
-def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None):
+def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None, packed=None):
     """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight (+ up to two addends summed in the GEMM's
     epilogue, further ones by accumulate launches); zero-padded input channels get zero.  out: write the result into this
-    NHWC view (it may be one of the addends: the epilogue reads an addend before it stores the sum)."""
+    NHWC view (it may be one of the addends: the epilogue reads an addend before it stores the sum).
+    packed: (operand, cin) of an already packed data-gradient operand (weight4 is then unused)."""
     n, cp, h, w = in_shape
-    cin = weight4.shape[1]
     ty = as_ymi(dy)
-    wd = pack_conv_dgrad(weight4, ty.c, stride, dtype)
+    if packed is not None:
+        wd, cin = packed
+    else:
+        cin = weight4.shape[1]
+        wd = pack_conv_dgrad(weight4, ty.c, stride, dtype)
     dx = out if (out is not None and tuple(out.shape) == (n, cp, h, w) and cp == cin) else empty_nhwc(n, cp, h, w, dtype, dy.device)
     dxv = dx
     if cp != cin:
@@ -562,17 +629,23 @@ def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None):
     return dx
 
 
-def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype):
+def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype, packed=None):
     """data gradient of a consumer of a (possibly joined) tensor: deposits (and returns None) unless it is the last consumer."""
     adds = join.arrive() if join is not None else []
     out = None
-    if adds is not None and join is not None and join.out is not None:
+    if adds is not None and join is not None and join.dst is not None:
+        # the tensor's gradient has a prepared place (a channel slice of its producer's gradient buffer: _ChanSplit2): the total goes there
+        cand = join.dst.view(dtype)
+        join.dst = None
+        if cand is not None and tuple(cand.shape) == tuple(in_shape) and _dense_ok(cand, dtype) and not (k == 1 and stride > 1):
+            out = cand
+    elif adds is not None and join is not None and join.out is not None:
         out, join.out = join.out, None
         if len(adds) < 2 and _dense_ok(out, dtype) and tuple(out.shape) == tuple(in_shape) and not (k == 1 and stride > 1):
             adds = list(adds) + [out]  # the contribution already in the buffer rides as an addend; the total replaces it
         else:
             out = None  # (left for _C2fSplit's own add)
-    dx = _dgrad(dy, weight4, k, stride, in_shape, dtype, adds, out)
+    dx = _dgrad(dy, weight4, k, stride, in_shape, dtype, adds, out, packed)
     if adds is None:
         join.deposit(dx)
         return None
@@ -690,6 +763,165 @@ def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
             _deferred_counters.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
+    return out
+
+
+class _GradBuffer:
+    """the gradient buffer of a tensor whose channel slices are consumed separately (_ChanSplit2): allocated when the first consumer's
+    data gradient needs its slice, so that every slice's gradient is WRITTEN where the whole tensor's gradient will be read."""
+
+    def __init__(self, shape, device):
+        self.shape, self.device, self.buf = tuple(shape), device, None
+
+    def get(self, dtype):
+        if self.buf is None:
+            n, c, h, w = self.shape
+            self.buf = empty_nhwc(n, c, h, w, dtype, self.device)
+        return self.buf if self.buf.dtype == dtype else None
+
+
+class _GradSlot:
+    __slots__ = ("gb", "lo", "hi")
+
+    def __init__(self, gb, lo, hi):
+        self.gb, self.lo, self.hi = gb, lo, hi
+
+    def view(self, dtype):
+        b = self.gb.get(dtype)
+        return None if b is None else b[:, self.lo : self.hi]
+
+
+class _ChanSplit2(torch.autograd.Function):
+    """(t[:, :c], t[:, c:]) of an NHWC tensor as two views whose gradients are formed IN PLACE in one buffer: each view carries a GradJoin
+    with a prepared destination (GradJoin.dst), its consumer's data-gradient GEMM writes its slice of the buffer, and backward hands the
+    buffer on without a copy (autograd's own slices would zero-fill two full tensors and add them).  Falls back to copies when a gradient
+    arrives somewhere else."""
+
+    @staticmethod
+    def forward(ctx, t, c):
+        ctx.c, ctx.shape = c, tuple(t.shape)
+        ctx.gb = _ChanSplit2.last = _GradBuffer(t.shape, t.device)  # (chan_split2 picks it up right after apply)
+        return t[:, :c], t[:, c:]
+
+    @staticmethod
+    def backward(ctx, ga, gb):
+        c = ctx.c
+        buf = ctx.gb.buf
+        ctx.gb.buf = None
+        n, ctot, h, w = ctx.shape
+        g0 = ga if ga is not None else gb
+        if buf is None or buf.dtype != g0.dtype:
+            buf = empty_nhwc(n, ctot, h, w, g0.dtype, g0.device)
+        for g, dst in ((ga, buf[:, :c]), (gb, buf[:, c:])):
+            if g is None:
+                dst.zero_()
+            elif not (g.data_ptr() == dst.data_ptr() and g.stride() == dst.stride() and g.dtype == dst.dtype):
+                check(L().ymi_copy(_byref(as_ymi(grad_nhwc(g, buf.dtype))), _byref(as_ymi(dst)), stream_ptr()), "copy")
+        return buf, None
+
+
+def chan_split2(t, c):
+    """-> (t[:, :c], t[:, c:]); in training each half is marked with a join whose total lands in the matching slice of ONE gradient buffer."""
+    a, b = _ChanSplit2.apply(t, int(c))
+    if torch.is_grad_enabled() and t.requires_grad:
+        gb, _ChanSplit2.last = getattr(_ChanSplit2, "last", None), None
+        if gb is not None:
+            for v, lo, hi in ((a, 0, int(c)), (b, int(c), t.shape[1])):
+                mark_join(v, 1, force=True)
+                j = join_of(v)
+                if j is not None:
+                    j.dst = _GradSlot(gb, lo, hi)
+    return a, b
+
+
+class _ConvBnActPair(torch.autograd.Function):
+    """two Conv blocks of the SAME input as one convolution with oA + oB output channels: Detect's sibling branches cv2[i][0] / cv3[i][0]
+    (reference head.py:44-59,71-72).  BatchNorm is per channel, so the result is exactly the two separate blocks; parameters stay the
+    reference's separate tensors (their packed operands lie side by side in the weight arena).  The data gradient is ONE GEMM with
+    K = taps * (oA + oB) (the GradJoin sum of the two branches disappears into the accumulator), the weight gradient one GEMM whose
+    [oA + oB, cin, k, k] result is handed out as two views."""
+
+    @staticmethod
+    def forward(ctx, x, wa, ga, ba, rma, rva, wb, gb, bb, rmb, rvb, stride, eps, momentum, act, join):
+        dtype = x.dtype
+        oa, i, k, _ = wa.shape
+        ob = wb.shape[0]
+        o = oa + ob
+        n, cp, h, w = x.shape
+        ho, wo = _conv_out_hw(h, w, k, stride)
+        dev = x.device
+        _note_use(wa, wb)
+        wp = pack_conv_fwd_pair(wa, wb, cp, dtype)
+        raw = empty_nhwc(n, o, ho, wo, dtype, dev)
+        out = empty_nhwc(n, o, ho, wo, dtype, dev)
+        stats = torch.empty((2, o), dtype=torch.float32, device=dev)
+        m = n * ho * wo
+        need = (L().ymi_conv2d_stat_blocks(m, o) * 2 * o + 2 * o) * 4
+        ws = workspace(need, dev, "conv")
+        check(
+            L().ymi_conv2d_bn_silu_fwd_pair(
+                _byref(as_ymi(x)), ptr(wp), o, oa, k, k, stride, ptr(ga), ptr(ba), ptr(rma), ptr(rva), ptr(gb), ptr(bb), ptr(rmb), ptr(rvb),
+                momentum, eps, act, _byref(as_ymi(raw)), _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream_ptr(),
+            ),
+            "conv2d_bn_silu_fwd_pair",
+        )
+        ctx.save_for_backward(x, wa, wb, ga, ba, gb, bb, raw, stats)
+        ctx.cfg = (stride, act, i)
+        ctx.join = join
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, wa, wb, ga, ba, gb, bb, raw, stats = ctx.saved_tensors
+        stride, act, cin = ctx.cfg
+        dtype = x.dtype
+        oa, _, k, _ = wa.shape
+        ob = wb.shape[0]
+        o = oa + ob
+        dev = x.device
+        dout = grad_nhwc(dout, dtype)
+        draw = empty_nhwc(*raw.shape, dtype, dev)
+        dgamma = torch.empty(o, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(o, dtype=torch.float32, device=dev)
+        ws = workspace(2048 * 2 * o * 4 + 256, dev, "bnbwd")
+        check(
+            L().ymi_bn_act_bwd_pair(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(ga), ptr(ba), ptr(gb), ptr(bb), oa, ptr(stats[0]), ptr(stats[1]), act,
+                                    _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
+            "bn_act_bwd_pair",
+        )
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wd = pack_conv_dgrad_pair(wa, wb, stride, dtype)
+            dx = _dgrad_joined(ctx.join, draw, None, k, stride, x.shape, dtype, packed=(wd, cin))
+        nig = ctx.needs_input_grad
+        dwa = dwb = None
+        if nig[1] or nig[6]:
+            # one GEMM for both weights; the two gradients are the halves of its [oA + oB, cin, k, k] result.  Deferred only when BOTH
+            # parameters adopt their half (a frozen one would leave its half's memory to the allocator before the batched slab sum runs)
+            dw, _ = _wgrad_maybe_async(x, draw, o, cin, k, stride, False, (wa, wb), pair_rows=oa)
+            dwa, dwb = (dw[:oa] if nig[1] else None), (dw[oa:] if nig[6] else None)
+        return (dx, dwa, dgamma[:oa], dbeta[:oa], None, None, dwb, dgamma[oa:], dbeta[oa:], None, None, None, None, None, None, None)
+
+
+def conv_bn_act_pair(x, conv_a, bn_a, conv_b, bn_b, act=ACT_SILU):
+    """train-mode act(BN_a(conv_a(x))) and act(BN_b(conv_b(x))) from ONE convolution -> [N, oA + oB, H', W'] (the first block's channels first).
+    conv_*: nn.Conv2d parameter containers of equal kernel / stride / input width; widths in whole 16-byte chunks."""
+    wa, wb = conv_a.weight, conv_b.weight
+    if wa.shape[1:] != wb.shape[1:] or conv_a.stride != conv_b.stride:
+        raise RuntimeError("conv_bn_act_pair: the two convolutions must share kernel size, stride and input width")
+    if bn_a.momentum is None or bn_b.momentum is None or bn_a.eps != bn_b.eps or bn_a.momentum != bn_b.momentum:
+        raise RuntimeError("conv_bn_act_pair: the two BatchNorms must share eps and momentum (initialize_weights sets them alike)")
+    ch = chunk_elems(x.dtype)
+    if wa.shape[0] % ch or wb.shape[0] % ch:
+        raise NotImplementedError(f"conv_bn_act_pair: output widths {wa.shape[0]} / {wb.shape[0]} must be multiples of {ch} in {x.dtype}")
+    out = _ConvBnActPair.apply(x, wa, bn_a.weight, bn_a.bias, bn_a.running_mean, bn_a.running_var, wb, bn_b.weight, bn_b.bias, bn_b.running_mean,
+                               bn_b.running_var, int(conv_a.stride[0]), float(bn_a.eps), float(bn_a.momentum), int(act), join_of(x))
+    for bn in (bn_a, bn_b):
+        if bn.num_batches_tracked is not None:
+            if _deferred_counters is not None:
+                _deferred_counters.append(bn.num_batches_tracked)
+            else:
+                bn.num_batches_tracked.add_(1)
     return out
 
 

@@ -100,7 +100,10 @@ typedef struct ymi_pack_desc {
     const float* src;
     void* dst_fwd;
     void* dst_dgrad;
-    int32_t o, i, kh, kw, ipad, opad, stride, _pad;
+    int32_t o, i, kh, kw, ipad, opad, stride;
+    int32_t ostride; /* row length of the data-gradient operand; 0 = opad.  With ostride > opad several weights fill one operand side by side: */
+    int32_t o_off;   /* ... this weight's first column (the merged operand of Detect's sibling convolutions cv2[i][0] / cv3[i][0], head.py:71-72) */
+    int32_t _pad;
 } ymi_pack_desc;
 int ymi_pack_conv_weights_batch(const void* descs_device, const int32_t* block_start_device, int32_t count, int32_t total_blocks,
                                 int32_t dtype, void* stream);
@@ -146,6 +149,20 @@ int ymi_conv2d_bn_silu_fwd(const ymi_tensor* x, const void* w_packed, int64_t co
 int ymi_bn_act_bwd(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* save_mean,
                    const float* save_invstd, const float* beta, int32_t act, const ymi_tensor* draw, float* dgamma, float* dbeta,
                    void* workspace, size_t workspace_bytes, void* stream);
+
+/* Two Conv blocks that read the SAME input as ONE convolution - the first convolutions of Detect's two branches, cv2[i][0] and cv3[i][0]
+ * (nn/modules/head.py:44-59,71-72): w_packed holds the first convolution's packed weights followed by the second's (output channels
+ * [0, split) / [split, cout)); BatchNorm is per channel, so with each half reading its own gamma / beta and updating its own running
+ * statistics the result equals the two separate blocks.  raw / out / save_mean / save_invstd cover all cout channels.  split % 4 == 0. */
+int ymi_conv2d_bn_silu_fwd_pair(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t split, int64_t kh, int64_t kw, int64_t stride,
+                                const float* gamma, const float* beta, float* running_mean, float* running_var, const float* gamma2,
+                                const float* beta2, float* running_mean2, float* running_var2, float momentum, float eps, int32_t act,
+                                const ymi_tensor* raw, const ymi_tensor* out, float* save_mean, float* save_invstd, void* workspace,
+                                size_t workspace_bytes, void* stream);
+/* ... and the backward of its BatchNorm + activation (as ymi_bn_act_bwd; dgamma / dbeta hold all channels, the first block's first). */
+int ymi_bn_act_bwd_pair(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* beta, const float* gamma2,
+                        const float* beta2, int64_t split, const float* save_mean, const float* save_invstd, int32_t act,
+                        const ymi_tensor* draw, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = conv_transpose(dy, w): operand packed by ymi_pack_conv_weight_dgrad.  Adjoint of conv.py:79. */
 int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
                         const ymi_tensor* dx, void* stream);
