@@ -53,6 +53,9 @@ class Conv(nn.Module):
 
     def forward(self, x, residual=None, out=None):
         """out: optional ops.OutSlot (train mode only): write the result into a slice of a concat buffer."""
+        if self.training and hasattr(self, "bn") and ops.first_conv_ok(x, self.conv, residual, out) and isinstance(self.act, nn.SiLU):
+            # the model's first layer on the caller's float32 NCHW image: direct kernel, no layout pass (csrc/first_conv.hip)
+            return ops.first_conv_bn_act(x, self.conv.weight, self.bn, self._act_code())
         x = ops.to_internal(x)
         k, s = self.conv.kernel_size[0], self.conv.stride[0]
         if not hasattr(self, "bn"):

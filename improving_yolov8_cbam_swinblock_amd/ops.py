@@ -766,6 +766,77 @@ def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
     return out
 
 
+class _FirstConvBnAct(torch.autograd.Function):
+    """The model's first Conv block on the caller's float32 NCHW image (reference yolov8.yaml:738 through conv.py:50-79): direct 3x3
+    stride-2 convolution (csrc/first_conv.hip) that reads the NCHW planes itself and leaves the NHWC bfloat16 copy of the image the
+    backward pass needs as a by-product - no layout pass, no K padding from 27 to 72.  The image receives no gradient."""
+
+    @staticmethod
+    def forward(ctx, img, weight, gamma, beta, running_mean, running_var, eps, momentum, act):
+        n, c, h, w = img.shape
+        o = weight.shape[0]
+        dt = torch.bfloat16
+        dev = img.device
+        ho, wo = _conv_out_hw(h, w, 3, 2)
+        _note_use(weight)
+        x8 = empty_nhwc(n, 8, h, w, dt, dev)
+        raw = empty_nhwc(n, o, ho, wo, dt, dev)
+        out = empty_nhwc(n, o, ho, wo, dt, dev)
+        stats = torch.empty((2, o), dtype=torch.float32, device=dev)
+        need = (2 * o + (L().ymi_first_conv_stat_blocks(n, h, w) + 64) * 2 * o) * 4
+        ws = workspace(need, dev, "conv")
+        check(
+            L().ymi_first_conv_bn_act_fwd(ptr(img), n, c, h, w, ptr(weight.detach()), o, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), momentum, eps,
+                                          act, _byref(as_ymi(x8)), _byref(as_ymi(raw)), _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(),
+                                          stream_ptr()),
+            "first_conv_bn_act_fwd",
+        )
+        ctx.save_for_backward(x8, weight, gamma, beta, raw, stats)
+        ctx.act = act
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x8, weight, gamma, beta, raw, stats = ctx.saved_tensors
+        dtype = x8.dtype
+        o, cin, k, _ = weight.shape
+        dev = x8.device
+        dout = grad_nhwc(dout, dtype)
+        draw = empty_nhwc(*raw.shape, dtype, dev)
+        dgamma = torch.empty(o, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(o, dtype=torch.float32, device=dev)
+        ws = workspace(2048 * 2 * o * 4 + 256, dev, "bnbwd")
+        check(
+            L().ymi_bn_act_bwd(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(beta), ctx.act,
+                               _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
+            "bn_act_bwd",
+        )
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dw, _ = _wgrad_maybe_async(x8, draw, o, cin, k, 2, False, (weight,))
+        return None, dw, dgamma, dbeta, None, None, None, None, None
+
+
+def first_conv_ok(x, conv, residual, slot):
+    """the direct first-layer kernel applies: a float32 NCHW image that needs no gradient, bfloat16 compute, 3x3 stride 2, <= 4 input channels."""
+    return (residual is None and slot is None and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
+            and x.shape[1] <= 4 and not x.requires_grad and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.in_channels == x.shape[1]
+            and conv.out_channels in (16, 32, 48, 64) and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and compute_dtype(x) == torch.bfloat16
+            and os.environ.get("YMI_FIRST_CONV", "1") != "0")
+
+
+def first_conv_bn_act(img, weight, bn, act=ACT_SILU):
+    if bn.momentum is None:
+        raise RuntimeError("BatchNorm with cumulative moving average (momentum=None) is not supported")
+    out = _FirstConvBnAct.apply(img, weight, bn.weight, bn.bias, bn.running_mean, bn.running_var, float(bn.eps), float(bn.momentum), int(act))
+    if bn.num_batches_tracked is not None:
+        if _deferred_counters is not None:
+            _deferred_counters.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
+    return out
+
+
 class _GradBuffer:
     """the gradient buffer of a tensor whose channel slices are consumed separately (_ChanSplit2): allocated when the first consumer's
     data gradient needs its slice, so that every slice's gradient is WRITTEN where the whole tensor's gradient will be read."""
