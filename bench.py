@@ -213,6 +213,9 @@ def main():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="torch.distributed backend of the gradient mean: nccl (= RCCL over xGMI, the measured configuration) or gloo "
                          "(rehearsal of the multi-rank path on fewer GPUs than ranks: ranks then share devices round-robin)")
+    ap.add_argument("--schedule", choices=["auto", "split", "tail"], default="auto",
+                    help="graph schedule: auto = one graph on one rank, three graphs with the bucket exchanges between them on several; split = "
+                         "the several-rank schedule also on one rank (what it costs without the collectives); tail = round 3's several-rank form")
     ap.add_argument("--sustained", type=int, default=200, help="graph replays of the sustained-throughput sub-record (0: skip)")
     ap.add_argument("--forward-only", action="store_true",
                     help="profiling aid: run ONLY the train-mode forward (north_star's target metric) - warm-up + `steps` graph replays - and print "
@@ -252,7 +255,7 @@ def main():
         rec["model"] = args.model
         print(json.dumps({"forward": rec}), flush=True)
         return
-    step = TrainStep(model, world_size=world, graph=use_graph)
+    step = TrainStep(model, world_size=world, graph=(args.schedule if (use_graph and args.schedule != "auto") else use_graph))
 
     for _ in range(args.warmup):
         step(batch)
@@ -372,6 +375,8 @@ def main():
                 "backend": ("rccl" if args.backend == "nccl" else "gloo") if args.gpus > 1 else None,
             },
             "hip_graph": bool(use_graph),
+            "schedule": ("one graph" if step.full_graph else "three graphs, bucket exchanges between them" if step.overlap_graphs else
+                         "forward+backward graph, eager reduction and update" if use_graph else "eager"),
             "gflop_per_image": round(gf_both, 2) if gf_both is not None else None,
             "model_tflops": round(value * gf_both / 1e3, 2) if gf_both is not None else None,
             "model_mfma_frac": round(value * gf_both / 1e3 / (PEAK_BF16_TFLOPS * args.gpus), 4) if gf_both is not None else None,

@@ -73,21 +73,28 @@ class GradientBuckets:
     (used when backward is a replayed HIP graph, which cannot call into RCCL).
     Usage: gb = GradientBuckets(model, world); ... loss.backward(); gb.finish()."""
 
-    def __init__(self, module, world_size, bucket_bytes=32 << 20, comm_dtype=None, overlap=True):
+    def __init__(self, module, world_size, bucket_bytes=32 << 20, comm_dtype=None, overlap=True, groups=None):
+        """groups: explicit buckets (lists of parameters, in the order their gradients become ready) instead of size-based ones - the
+        split-graph schedule of engine.trainer.TrainStep uses [head parameters], [backbone parameters]."""
         self.world = world_size
         self.comm_dtype = comm_dtype
         params = [p for p in module.parameters() if p.requires_grad]
         params.reverse()  # gradients become ready roughly in reverse registration order
         self.buckets = []
-        cur, size = [], 0
-        for p in params:
-            cur.append(p)
-            size += p.numel() * 4
-            if size >= bucket_bytes:
+        if groups is not None:
+            self.buckets = [list(g) for g in groups if len(g)]
+            if sorted(id(p) for b in self.buckets for p in b) != sorted(id(p) for p in params):
+                raise ValueError("GradientBuckets: the groups must partition the trainable parameters")
+        else:
+            cur, size = [], 0
+            for p in params:
+                cur.append(p)
+                size += p.numel() * 4
+                if size >= bucket_bytes:
+                    self.buckets.append(cur)
+                    cur, size = [], 0
+            if cur:
                 self.buckets.append(cur)
-                cur, size = [], 0
-        if cur:
-            self.buckets.append(cur)
         self._where = {}
         self._flat = []
         self._views = []  # per bucket: slices of the flat buffer shaped like the parameters
@@ -125,10 +132,39 @@ class GradientBuckets:
         if self._pending[bi] == 0:
             self._launch(bi)
 
-    def finish(self, grads_of=None, force=False):
+    def flat_views(self, bi):
+        """the slices of bucket bi's flat buffer, shaped like its parameters (static storage: a captured graph may write them)."""
+        return self._views[bi]
+
+    def start(self, bi, packed=True):
+        """start bucket bi's all-reduce; packed: its gradients already lie in the flat buffer (written there by a captured multi-tensor
+        copy) - else they are packed from .grad first.  The collective is issued on the communicator's stream behind whatever the
+        current stream has enqueued so far, so work enqueued afterwards (the backbone's backward graph) overlaps it."""
+        if self.world == 1 and not (dist.is_available() and dist.is_initialized()):
+            return  # one rank, no process group (the schedule's one-rank test form): nothing to exchange
+        if packed:
+            self._work[bi] = dist.all_reduce(self._flat[bi], op=dist.ReduceOp.SUM, async_op=True)
+        else:
+            self._launch(bi)
+
+    def wait_all(self, divide=True):
+        """wait for the started buckets (the current stream waits; the host does not block on NCCL) and point .grad at the flat slices.
+        divide=False leaves the SUM there: the fused optimizer step scales by 1 / world itself (FusedSGD.world)."""
+        for bi, b in enumerate(self.buckets):
+            if self._work[bi] is not None:
+                self._work[bi].wait()
+                self._work[bi] = None
+            if divide:
+                self._flat[bi].div_(self.world)
+            for p, v in zip(b, self._views[bi]):
+                p.grad = v if v.dtype == p.dtype else v.to(p.dtype)
+            self._pending[bi] = len(b)
+
+    def finish(self, grads_of=None, force=False, divide=True):
         """wait for every bucket and leave grad = sum / world in .grad (as views of the flat buffers: no copy back);
         re-arm for the next step.  grads_of: optional {param: gradient tensor} to reduce instead of .grad.
-        force: run the collectives even on one rank (the RCCL smoke test of a one-GPU box)."""
+        force: run the collectives even on one rank (the RCCL smoke test of a one-GPU box).
+        divide=False: leave the SUM (engine.trainer: the fused optimizer step scales by 1 / world itself)."""
         if self.world == 1 and not force:
             return
         for bi, b in enumerate(self.buckets):
@@ -143,7 +179,8 @@ class GradientBuckets:
                 self._launch(bi, src)
         for bi, b in enumerate(self.buckets):
             self._work[bi].wait()
-            self._flat[bi].div_(self.world)
+            if divide:
+                self._flat[bi].div_(self.world)
             for p, v in zip(b, self._views[bi]):
                 p.grad = v if v.dtype == p.dtype else v.to(p.dtype)
             self._work[bi] = None

@@ -94,7 +94,7 @@ class FusedSGD:
             {"params": g_norm, "lr": lr, "initial_lr": lr, "momentum": momentum, "nesterov": nesterov, "weight_decay": 0.0, "dampening": 0},
         ]
         self.max_norm = float(max_norm) if max_norm else 0.0
-        self.world = 1  # gradients arrive already averaged over ranks (GradientBuckets.finish); hyper[11] = 1 / world stays 1
+        self.world = 1  # gradients are scaled by 1 / world inside the kernels (hyper[11]): TrainStep hands over the SUM over ranks and sets this
         self.ema = ema
         self.sgd = sgd
         self._state = None

@@ -64,8 +64,16 @@ class TrainStep:
     graph=True replays the step as a HIP graph (every kernel of libyolo_mi355 only enqueues on the stream it is
     given, so the capture is legal; needs static shapes: batch["max_boxes"] must be set):
       * one rank: the whole step (forward, loss, backward, clip, update, EMA) is one graph;
-      * several ranks: forward + loss + backward are one graph; the RCCL gradient mean and the fused update run eagerly
-        after the replay (half a dozen launches), because RCCL calls are not captured.
+      * several ranks (or graph="split": the same schedule on one rank, for tests): THREE graphs with the RCCL calls - which cannot
+        be captured - between them, so that the exchange overlaps compute as the reference's DDP reducer does (trainer.py:278):
+          G1  forward + loss + the HEAD's backward (down to the backbone / head boundary of the YAML), head gradients copied
+              into bucket 0's flat buffer                     -> all-reduce of bucket 0 starts (RCCL's own stream)
+          G2  the BACKBONE's backward, its gradients copied into bucket 1's flat buffer (runs beside bucket 0's all-reduce)
+                                                              -> all-reduce of bucket 1 starts
+          G3  clip + update + EMA reading the gradient SUMS from the flat buffers (the step scales by 1 / world itself)
+        The backward is split with torch.autograd.grad at the boundary tensors (BaseModel.boundary_layers); gradient joins of
+        boundary tensors (ops.GradJoin) carry the head's contribution into the backbone's pass.
+      * graph="tail": the round-3 multi-rank form (forward + backward as one graph, gradient mean and update eager behind it).
     Learning rates / momentum changed through `opt.param_groups` reach a replayed graph: they are read from a device
     array (`FusedSGD.sync_hyper`).
 
@@ -83,9 +91,21 @@ class TrainStep:
         self.ema = ModelEMA(model) if ema is True else (ema or None)
         self.opt = build_optimizer(model, name=optimizer, lr=lr, momentum=momentum, decay=decay, ema=self.ema)
         self.use_graph = bool(graph)
-        self.full_graph = self.use_graph and world_size == 1 and graph != "split"  # graph="split": the multi-rank form on one rank
-        self.buckets = GradientBuckets(model, world_size, bucket_bytes, overlap=not self.use_graph)
+        self.full_graph = self.use_graph and world_size == 1 and graph not in ("split", "tail")
+        self.overlap_graphs = self.use_graph and not self.full_graph and graph != "tail"
         self.params = [p for p in model.parameters() if p.requires_grad]
+        groups = None
+        if self.overlap_graphs:
+            # bucket 0 = the head's parameters (their gradients are complete when G1 ends), bucket 1 = the backbone's
+            nb = len(model.yaml["backbone"])
+            head_ids = {id(p) for m in model.model if m.i >= nb for p in m.parameters()}
+            self._head_params = [p for p in reversed(self.params) if id(p) in head_ids]
+            self._back_params = [p for p in reversed(self.params) if id(p) not in head_ids]
+            self._boundary = model.boundary_layers()
+            groups = [self._head_params, self._back_params]
+        self.buckets = GradientBuckets(model, world_size, bucket_bytes, overlap=not self.use_graph, groups=groups)
+        # the buckets hold gradient SUMS over ranks; the fused step applies 1 / world (hyper[11]) - no divide launches
+        self.opt.world = world_size
         self._graph = None
         self._static = None
         self._static_items = None
@@ -107,15 +127,18 @@ class TrainStep:
             # several ranks: the process group's watchdog thread polls its events while this thread captures; only
             # this thread's calls may invalidate the capture
             mode = "global" if self.world == 1 else "thread_local"
-            with torch.cuda.graph(self._graph, capture_error_mode=mode):
-                if self.full_graph:
-                    self._static_items = self.eager_step(self._static)
-                else:
-                    self._static_items = self._forward_backward(self._static)
-            if not self.full_graph:  # the gradients the replays rewrite in place
-                self._graph_grads = {p: p.grad for p in self.params if p.grad is not None}
-            elif self.ema is not None:
-                self.opt.count_updates(-1)  # the capture recorded the update without running it
+            if self.overlap_graphs:
+                self._capture_overlap(mode)
+            else:
+                with torch.cuda.graph(self._graph, capture_error_mode=mode):
+                    if self.full_graph:
+                        self._static_items = self.eager_step(self._static)
+                    else:
+                        self._static_items = self._forward_backward(self._static)
+                if not self.full_graph:  # the gradients the replays rewrite in place
+                    self._graph_grads = {p: p.grad for p in self.params if p.grad is not None}
+                elif self.ema is not None:
+                    self.opt.count_updates(-1)  # the capture recorded the update without running it
         else:
             for k, v in batch.items():
                 if torch.is_tensor(v) and v is not self._static[k]:
@@ -124,16 +147,103 @@ class TrainStep:
                     self._static[k].copy_(v)
                 elif not torch.is_tensor(v) and v != self._static[k]:
                     raise ValueError(f"graph=True: batch['{k}'] = {v!r} differs from the captured value {self._static[k]!r}")
-        if self.full_graph:
+        if self.full_graph or self.overlap_graphs:
             self.opt.sync_hyper()  # scheduler changes reach the captured update through the device array
         self._graph.replay()
         if self.full_graph:
             if self.ema is not None:
                 self.opt.count_updates(+1)  # the captured step advanced the device counter
+        elif self.overlap_graphs:
+            self.buckets.start(0)       # the head's gradient sums travel ...
+            self._graph2.replay()       # ... while the backbone's backward runs
+            self.buckets.start(1)
+            self.buckets.wait_all(divide=False)  # the current stream waits for both; .grad = the flat buffers' slices
+            self._graph3.replay()
+            if self.ema is not None:
+                self.opt.count_updates(+1)
+            self.opt.zero_grad(set_to_none=True)
         else:
             self._reduce_and_update(self._graph_grads)
             self.opt.zero_grad(set_to_none=True)  # drops references only: the graph owns its gradient buffers
         return self._static_items
+
+    # ---- the three-graph schedule -----------------------------------------------------------------------------------------------
+    def _head_pass(self, batch):
+        """forward + loss + the backward of everything behind the backbone / head boundary (the head reads detached leaves of the
+        boundary tensors: BaseModel._predict_once) -> (loss items, head gradients aligned with self._head_params,
+        [(boundary tensor, gradient the head formed for it)])."""
+        model = self.model
+        model.train()
+        model._taps = dict(self._boundary)
+        try:
+            with torch.autocast("cuda", dtype=self.dtype, enabled=self.dtype != torch.float32):
+                loss, items = model(batch)
+            taps = model._taps
+        finally:
+            model._taps = None
+        if self._seed is None or self._seed.device != loss.device:
+            self._seed = torch.full((3,), float(self.world), dtype=torch.float32, device=loss.device)
+        pairs = [v for v in taps.values() if isinstance(v, tuple)]
+        leaves = [leaf for _, leaf in pairs]
+        # torch.autograd.grad, not backward(): the leaves are channel slices of concat buffers (not dense), and AccumulateGrad would
+        # re-lay every gradient it stores for them out as NCHW-contiguous copies; captured gradients are handed over as they are
+        with ops.deferred_wgrad(True):
+            grads = torch.autograd.grad([loss], leaves + self._head_params, [self._seed], allow_unused=True)
+        return items, list(grads[len(leaves):]), [(orig, g) for (orig, _), g in zip(pairs, grads[: len(leaves)])]
+
+    def _backbone_pass(self, pairs):
+        """the backbone's backward, from the boundary tensors with the gradients the head left in their leaves.  A boundary tensor that
+        also has backbone consumers carries a gradient join: the head's gradient is deposited there and the backbone consumer that
+        arrives last adds it in its data-gradient epilogue; the others are roots of the pass."""
+        roots, grads = [], []
+        for orig, g in pairs:
+            if g is None:
+                continue
+            j = ops.join_of(orig)
+            if j is not None:
+                adds = j.arrive()
+                if adds is None:
+                    j.deposit(g)
+                    continue
+                g = ops._accumulate(g, adds) if adds else g  # (no backbone consumer left to arrive: the head's gradient is the total)
+            roots.append(orig)
+            grads.append(g)
+        with ops.deferred_wgrad(True):
+            torch.autograd.backward(roots, grads)
+
+    def _pack(self, bi, params, grads):
+        """gradients -> the slices of bucket bi's flat buffer (one multi-tensor copy; parameters without a gradient keep zeros there)."""
+        views = self.buckets.flat_views(bi)
+        where = {id(p): v for p, v in zip(self.buckets.buckets[bi], views)}
+        dst, src = [], []
+        for p, g in zip(params, grads):
+            if g is not None and not (g.data_ptr() == where[id(p)].data_ptr() and g.dtype == where[id(p)].dtype):  # (weight gradients are born there: ops.grad_arena)
+                dst.append(where[id(p)])
+                src.append(g if g.dtype == where[id(p)].dtype else g.to(where[id(p)].dtype))
+        if dst:
+            torch._foreach_copy_(dst, src)
+
+    def _capture_overlap(self, mode):
+        b = self._static
+        # conv / linear weight gradients are written straight into the flat buckets (ops.grad_arena): only the small vectors (BatchNorm
+        # and LayerNorm parameters, biases, the paired Detect weights) are copied there
+        arena = {id(p): v for bi in range(len(self.buckets.buckets)) for p, v in zip(self.buckets.buckets[bi], self.buckets.flat_views(bi)) if p.dim() >= 2}
+        with torch.cuda.graph(self._graph, capture_error_mode=mode), ops.grad_arena(arena):
+            self._static_items, hg, pairs = self._head_pass(b)
+            self._pack(0, self._head_params, hg)
+        del hg
+        self._graph2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph2, pool=self._graph.pool(), capture_error_mode=mode), ops.grad_arena(arena):
+            self._backbone_pass(pairs)
+            self._pack(1, self._back_params, [p.grad for p in self._back_params])
+        del pairs
+        self.buckets.wait_all(divide=False)  # (nothing in flight: points .grad at the flat slices the update graph will read)
+        self._graph3 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph3, pool=self._graph.pool(), capture_error_mode=mode):
+            self.opt.step(None)
+        if self.ema is not None:
+            self.opt.count_updates(-1)  # captured, not executed
+        self.opt.zero_grad(set_to_none=True)
 
     def _forward_backward(self, batch):
         self.model.train()
@@ -152,7 +262,7 @@ class TrainStep:
         return items
 
     def _reduce_and_update(self, grads_of=None):
-        self.buckets.finish(grads_of)  # world > 1: leaves the mean in .grad (views of the flat buckets)
+        self.buckets.finish(grads_of, divide=False)  # world > 1: leaves the SUM in .grad (views of the flat buckets); the step scales by 1 / world
         self.opt.step(grads_of if self.world == 1 else None)
 
     def eager_step(self, batch):

@@ -138,6 +138,12 @@ class BaseModel(nn.Module):
         straight into their slice of its buffer (no copies for conv.py:683 `torch.cat`), and a layer output with several
         consumers carries an ops.GradJoin, so its gradient sum forms in a consumer's kernel instead of autograd adds."""
         y = []
+        # engine.trainer's split backward: `_taps` = {boundary layer: number of head layers that read it}.  The head then reads a DETACHED
+        # leaf of every boundary tensor, so the loss's autograd graph ends there (first pass: head only); the backbone's pass starts from
+        # the originals with the leaves' gradients.  Filled with {layer: (original, leaf)}.
+        taps = getattr(self, "_taps", None)
+        nb_layers = len(self.yaml["backbone"]) if taps is not None else 0
+        leaf_of = {}
         ops.new_forward_epoch()  # (weights used twice within ONE forward are shared: their gradients are never deferred)
         self._begin_weight_arena(x)
         plan = self._graph_plan() if (self.training and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda) else None
@@ -146,6 +152,8 @@ class BaseModel(nn.Module):
             for m in self.model:
                 if m.f != -1:
                     x = y[m.f] if isinstance(m.f, int) else [x if j == -1 else y[j] for j in m.f]
+                if leaf_of and m.i >= nb_layers:  # a head layer: boundary tensors are read through their detached leaves
+                    x = [leaf_of.get(id(t), t) for t in x] if isinstance(x, list) else leaf_of.get(id(x), x)
                 if split_head and isinstance(m, Detect):
                     return SplitPreds(*m.forward_split(x))
                 if plan is None:
@@ -165,8 +173,31 @@ class BaseModel(nn.Module):
                     # only on the loss path, where every Detect input is known to receive a gradient: a join waits for ALL
                     # its consumers, and a caller of model(img) may back-propagate through some of the outputs only
                     ops.mark_join(x, plan["consumers"].get(m.i, 1))
+                if taps is not None and m.i in taps and torch.is_tensor(x) and x.requires_grad:
+                    heads = taps[m.i]
+                    leaf = x.detach().requires_grad_(True)
+                    ops.mark_join(leaf, heads)
+                    j = ops.join_of(x)
+                    if j is not None:
+                        j.n = j.n - heads + 1  # the head's consumers arrive as ONE deposit: the leaf's gradient (TrainStep._backbone_pass)
+                    leaf_of[id(x)] = leaf
+                    taps[m.i] = (x, leaf)
                 y.append(x if m.i in self.save else None)
         return x
+
+    def boundary_layers(self):
+        """indices of the backbone layers whose output a head layer reads (the YAML's `backbone` / `head` lists, reference
+        yolov8.yaml:736-776): every edge from the backbone into the head.  engine.trainer splits the backward pass there, so that the
+        head's gradients can be on their way over xGMI while the backbone's are still being computed."""
+        nb = len(self.yaml["backbone"])
+        out = {}
+        for m in self.model:
+            if m.i >= nb:
+                for j in ([m.f] if isinstance(m.f, int) else m.f):
+                    j = m.i - 1 if j == -1 else j
+                    if j < nb:
+                        out[j] = out.get(j, 0) + (2 if (isinstance(m, Detect) and not m.pair_ok) else 1)
+        return dict(sorted(out.items()))  # {boundary layer: number of head consumers of its output}
 
     def _graph_plan(self):
         """static facts of the layer graph, computed once: {"slot": {producer layer: (concat layer, channel offset, concat

@@ -295,14 +295,43 @@ def _conv_out_hw(h, w, k, s):
     return (h + 2 * p - k) // s + 1, (w + 2 * p - k) // s + 1
 
 
+# Where weight gradients should be WRITTEN: {id(parameter): float32 tensor of the parameter's shape}.  engine.trainer's several-rank
+# schedule registers the slices of its flat all-reduce buckets here, so that a weight gradient is born inside its bucket and no pack
+# copy of the 53.6 MB of gradients is needed before the exchange (None: fresh tensors).
+_grad_arena = None
+
+
+class grad_arena:
+    def __init__(self, views):
+        self.views = views
+
+    def __enter__(self):
+        global _grad_arena
+        self.prev, _grad_arena = _grad_arena, self.views
+        return self
+
+    def __exit__(self, *exc):
+        global _grad_arena
+        _grad_arena = self.prev
+        return False
+
+
+def _new_dw(cout, cin, k, dev, params, pair_rows):
+    if _grad_arena is not None and not pair_rows and params and params[0] is not None:
+        v = _grad_arena.get(id(params[0]))
+        if v is not None and v.numel() == cout * cin * k * k and v.dtype == torch.float32 and v.is_contiguous() and v.device == dev:
+            return v.view(cout, cin, k, k)
+    return torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
+
+
 def _wgrad(x, dy, cout, cin, k, stride, want_bias, params=(), pair_rows=None):
     """-> (dw [cout, cin, k, k] f32, dbias [cout] f32 | None).  params: the parameters these gradients belong to.
     pair_rows: params are TWO weights whose gradients are the row ranges [0, pair_rows) and [pair_rows, cout) of dw (_ConvBnActPair)."""
     if _deferred["on"] and _in_backward() and _adoptable(params) and not _deferred_twice(params):
         owner = (params[0], params[1], int(pair_rows)) if pair_rows else (params[0] if params else None)
-        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner)
+        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner, _new_dw(cout, cin, k, x.device, params, pair_rows))
     dev = x.device
-    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
+    dw = _new_dw(cout, cin, k, dev, params, pair_rows)
     ty, tx = as_ymi(dy), as_ymi(x)
     db = torch.empty(ty.c, dtype=torch.float32, device=dev) if want_bias else None  # (column sums of every channel of dy, padded ones included)
     need = L().ymi_conv2d_bwd_weight_workspace(ty.n * ty.h * ty.w, ty.c, tx.c, k, k)
@@ -473,6 +502,8 @@ def _flush_wgrads():
             # a cloned half cannot be redirected (the sum is one write of the whole tensor), so that case is refused loudly
             pa, pb, rows = owner
             per_row = rec.cin_real * rec.ntaps * 4
+            if pa.grad is None and pb.grad is None:
+                continue  # (torch.autograd.grad: the two views are handed to the caller as they are, nothing was accumulated)
             ok = (pa.grad is not None and pb.grad is not None and pa.grad.data_ptr() == rec.dw and pb.grad.data_ptr() == rec.dw + rows * per_row)
             if not ok:
                 raise RuntimeError("deferred weight gradient of a convolution pair: AccumulateGrad did not adopt both halves of the result")
@@ -495,7 +526,7 @@ def _flush_wgrads():
     del keep
 
 
-def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
+def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None, dw=None):
     """as _wgrad, with the slab sum left to the end of the backward pass.  Slabs and operands stay alive in _deferred['keep']
     until the flush has been enqueued; the gradient tensor itself is owned by autograd (see _flush_wgrads).  owner: the weight."""
     task = torch._C._current_graph_task_id()
@@ -506,7 +537,8 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None):
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
         _deferred["task"] = task
     dev = x.device
-    dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
+    if dw is None:
+        dw = torch.empty((cout, cin, k, k), dtype=torch.float32, device=dev)
     ty, tx = as_ymi(dy), as_ymi(x)
     db = torch.empty(ty.c, dtype=torch.float32, device=dev) if want_bias else None
     need = L().ymi_conv2d_bwd_weight_workspace(ty.n * ty.h * ty.w, ty.c, tx.c, k, k)

@@ -27,9 +27,11 @@ pytestmark = pytest.mark.gpu
 CONV_BOUND = 1e-3
 # Weight gradients: the split-K partial sums (one per pixel split, a float32 sum over >= 256 pixels) leave wgrad_kernel as
 # bfloat16 slabs and are summed in float32 (csrc/wgrad.hip, round 3: half the slab traffic); the oracle has no such storage
-# point.  One rounding of a partial is 1.1e-3 of ITS magnitude; measured on the sum: 1.7e-3 with a handful of splits (these
-# small cases), less with the 28-85 splits of the bs-32 layers.  float32 parity mode keeps float32 slabs.
-WGRAD_BOUND = 4e-3
+# point.  One rounding of a partial is 1.1e-3 of ITS magnitude; on the sum of a zero-mean gradient that is 1.7e-3 whatever the number
+# of splits (measured 1.66e-3 from 16 to 85 slabs: test_wgrad_bf16_slabs_at_bs32_model_shapes).  Launches with fewer than 16 splits
+# keep float32 slabs (round 4: they write little slab traffic anyway; 1e-5 .. 5e-5 there), and the bound is 2e-3 for every case.
+# float32 parity mode keeps float32 slabs.
+WGRAD_BOUND = 2e-3
 FWD_BOUND = 4e-3
 GRAD_BOUND = 1e-2
 
@@ -99,6 +101,38 @@ def test_conv_block_bf16_vs_matched_oracle(cin, cout, k, s, hw):
         errs[n] = rel(a, q(b) if n == "x" else b)   # the product stores the input gradient in bf16; the oracle's leaf gradient is not a stored tensor
     print(f"\n[matched conv {cin}->{cout} k{k} s{s} {hw}] " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()))
     assert all(e <= (WGRAD_BOUND if n == "w" else CONV_BOUND) for n, e in errs.items()), errs
+
+
+@pytest.mark.parametrize("cin,cout,k,hw", [(128, 128, 3, 80), (64, 64, 3, 160), (256, 128, 1, 80)])
+def test_wgrad_bf16_slabs_at_bs32_model_shapes(cin, cout, k, hw):
+    """the weight gradient at three layer shapes of the bs-32 step (dozens of bfloat16 first-level slabs per launch) against the matched
+    oracle's float32 sum: <= 2e-3.  Measured 1.66e-3 at all three - the same as a launch with 16 slabs: for a zero-mean gradient the
+    partial sums are as large as the total divided by sqrt(splits), so the relative error of the sum of rounded partials does NOT fall
+    with the number of splits (round 3's comment claimed it would); it is one bfloat16 rounding's worth, 1.1e-3 x ~1.5, whatever the count."""
+    import oracle.modules as OM
+    from oracle import quant
+    from improving_yolov8_cbam_swinblock_amd.nn.modules import Conv
+
+    torch.manual_seed(cin + cout + k)
+    o = OM.Conv(cin, cout, k, 1)
+    _bn_defaults(o, randomize=True)
+    quant.round_weights_(o)
+    m = Conv(cin, cout, k, 1)
+    _bn_defaults(m)
+    m.load_state_dict(o.state_dict())
+    m = m.to(dev()).train()
+    o.train()
+    x = q(torch.randn(32, cin, hw, hw))
+    gy = q(torch.randn(32, cout, hw, hw))
+    with quant.storage(torch.bfloat16):
+        yo = o(x)
+        (gw,) = torch.autograd.grad(yo, [o.conv.weight], gy)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        yg = m(x.to(dev()))
+    (gg,) = torch.autograd.grad(yg, [m.conv.weight], gy.to(dev()).to(yg.dtype))
+    e = rel(gg, gw)
+    print(f"\n[bs-32 wgrad {cin}->{cout} k{k} {hw}] dW {e:.2e}")
+    assert e <= 2e-3, e
 
 
 def _bn_defaults(m, randomize=False):

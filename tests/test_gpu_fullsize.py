@@ -126,11 +126,12 @@ def test_hip_graph_step_matches_eager_and_is_isolated(bs, sz):
 
     losses, params = {}, {}
     probe = ("model.0.conv.weight", "model.7.attn.in_proj_weight", "model.10.sa.conv.weight", "model.22.cv2.bn.weight", "model.26.cv3.0.2.bias")
-    # "split": forward + loss + backward as a graph, gradient reduction / clip / update eager (the multi-rank form)
-    for mode in ("eager", "graph", "split"):
+    # "split": the multi-rank schedule on one rank - three graphs (forward + head backward | backbone backward | update) with the
+    # bucket exchanges between them; "tail": round 3's form (forward + backward graph, eager reduction / update behind it)
+    for mode in ("eager", "graph", "split", "tail"):
         torch.manual_seed(0)
         model = DetectionModel("yolov8s.yaml", ch=3, nc=1).to(dev())
-        step = TrainStep(model, world_size=1, lr=0.01, graph={"eager": False, "graph": True, "split": "split"}[mode])
+        step = TrainStep(model, world_size=1, lr=0.01, graph={"eager": False, "graph": True, "split": "split", "tail": "tail"}[mode])
         batch = synthetic_batch(bs, sz, dev(), 1)
         out = []
         for i in range(10 if mode == "eager" else 7):
@@ -155,7 +156,8 @@ def test_hip_graph_step_matches_eager_and_is_isolated(bs, sz):
     # identical kernels on identical weights, deterministic: equal to float noise (2e-2 covers bf16 re-association only)
     torch.testing.assert_close(losses["graph"], losses["eager"][3:10], rtol=2e-2, atol=2e-2)
     torch.testing.assert_close(losses["split"], losses["eager"][3:10], rtol=2e-2, atol=2e-2)
-    for mode in ("graph", "split"):  # after 10 updates each: the replicas of the three schedules still agree
+    torch.testing.assert_close(losses["tail"], losses["eager"][3:10], rtol=2e-2, atol=2e-2)
+    for mode in ("graph", "split", "tail"):  # after 10 updates each: the replicas of the four schedules still agree
         for k in probe:
             a, b = params[mode][k], params["eager"][k]
             err = float((a - b).norm() / b.norm().clamp(min=1e-9))
@@ -309,7 +311,7 @@ def _ddp_worker(rank, world, port, graph, q):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("graph", [False, True], ids=["eager_overlapped", "graph_plus_eager_tail"])
+@pytest.mark.parametrize("graph", [False, True, "tail"], ids=["eager_overlapped", "three_graphs_overlapped", "graph_plus_eager_tail"])
 def test_two_rank_training_keeps_replicas_identical(graph):
     """2 ranks (gloo over CUDA tensors, one GPU): after 5 steps on different shards the replicas hold identical
     parameters (gradient mean applied on both) and the losses differ per shard."""
