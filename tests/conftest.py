@@ -142,5 +142,6 @@ def check_update_steps(d, init_state, states, ema_states, step_tol=(2e-3, 5e-2))
                     worst.append((kind, step, n, float((dg - dr).norm() / dr.norm())))
                 prev_ref[n], prev_got[n] = ref, got
             err = (tot_e / max(tot_r, 1e-30)) ** 0.5
+            print(f"[update steps] {'parameters' if kind == 'p' else 'EMA'} step {step}: relative error of the update {err:.2e} (bound {step_tol[step]:.0e})")
             assert err <= step_tol[step], (kind, step, err, sorted(worst, key=lambda w: -w[3])[:5])
     return worst

@@ -201,10 +201,14 @@ def test_train_steps_match_reference_trainer_fixture(name, fixture, lr, momentum
         # step 0: identical weights on both sides; step 1: weights 1e-7 apart, amplified by the tiny model's 2-image BatchNorm
         # (AdamW: the first update is lr * g / (|g| + 1e-8) - a gradient entry within float32 noise of zero takes a full-size step in a
         # direction that noise decides - so its second step starts from weights that differ in those entries: 5e-2 on the second norm)
-        assert abs(step.opt.grad_norm() - meta["norms"][i]) <= ((1e-3, 1e-2) if name == "SGD" else (1e-3, 5e-2))[i] * meta["norms"][i]
+        print(f"[{name} step {i}] gradient norm {step.opt.grad_norm():.6f} reference {meta['norms'][i]:.6f} relative {abs(step.opt.grad_norm() - meta['norms'][i]) / meta['norms'][i]:.2e}")
+        # bounds = twice what the final round-4 run measured (SGD 5.8e-5 / 2.4e-3, AdamW 5.8e-5 / 2.3e-2; the kernels are deterministic)
+        assert abs(step.opt.grad_norm() - meta["norms"][i]) <= ((1.2e-4, 5e-3) if name == "SGD" else (1.2e-4, 5e-2))[i] * meta["norms"][i]
         states.append({k: v.detach().cpu().clone() for k, v in model.state_dict().items()})
         ema_states.append({k: v.detach().cpu().clone() for k, v in step.ema.ema.state_dict().items()})
-    check_update_steps(d, init, states, ema_states, step_tol=(2e-3, 5e-2) if name == "SGD" else (2e-2, 1e-1))
+    # updates: measured 3.4e-5 / 9.6e-4 (SGD) and 5.9e-3 / 2.0e-2 (AdamW, whose sign-like first update amplifies float32 noise in
+    # near-zero gradient entries); bounds = twice that (round 3: 2e-3 / 5e-2 and 2e-2 / 1e-1)
+    check_update_steps(d, init, states, ema_states, step_tol=(7e-5, 2e-3) if name == "SGD" else (1.2e-2, 4e-2))
     assert step.ema.updates == meta["ema_updates"]
 
 
