@@ -76,8 +76,10 @@ _SIGNATURES = {
         [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _vp, _vp, _vp, _sz, _vp],
     ),
     "ymi_first_conv_stat_blocks": (_c_i64, [_c_i64, _c_i64, _c_i64]),
-    "ymi_first_conv_bn_act_fwd": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _TP, _vp, _vp,
+    "ymi_first_conv_bn_act_fwd": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _vp, _vp,
                                            _vp, _sz, _vp]),
+    "ymi_first_conv_bwd_workspace": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64]),
+    "ymi_first_conv_bn_act_bwd": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "ymi_bn_act_bwd_pair": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i64, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_data": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
     "ymi_conv2d_bwd_data_add": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp]),

@@ -271,6 +271,16 @@ int ymi_chan_reduce_final(const float* part, int blocks, int C, float* out0, flo
     return YMI_OK;
 }
 
+// final pass of a BatchNorm + activation backward whose first stage ran elsewhere (csrc/first_conv.hip): sums `blocks` partial rows
+// [block][2][C] (dz, dz * xhat) into dbeta / dgamma and writes the apply pass's coefficients [a0 | a1 | c0 | c1 | c2][C]
+int ymi_bn_bwd_final(const float* part, int blocks, int C, const float* gamma, const float* beta, const float* mean, const float* inv, float inv_count,
+                     float* dgamma, float* dbeta, float* coef, hipStream_t stream) {
+    hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, stream, part, blocks, C, dbeta, dgamma,
+                       BnCoefArgs{gamma, beta, mean, inv, inv_count, coef, GammaBeta2{nullptr, nullptr, 0}});
+    YMI_CHECK_LAUNCH("bn_bwd_final");
+    return YMI_OK;
+}
+
 extern "C" int ymi_colsum(const ymi_tensor* x, float* out, void* workspace, size_t workspace_bytes, void* stream) {
     YMI_CHECK_ARG(ymi_tensor_ok(x) && out && workspace, "colsum: args");
     const size_t need = (size_t)reduce_blocks(ymi_pixels(x), (int)x->c) * 2 * x->c * sizeof(float);

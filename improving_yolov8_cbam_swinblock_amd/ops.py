@@ -518,6 +518,8 @@ def _flush_wgrads():
         tab = _deferred["table"] = torch.empty(max(n, 128) * ctypes.sizeof(_lib.WgradPending), dtype=torch.uint8, device=dev)
     arr = (_lib.WgradPending * n)(*recs)
     if _async["on"]:  # the GEMMs ran on the side stream: the sum follows them there (joined by async_wgrad's exit)
+        # (slabs produced on the CURRENT stream - the first layer's fused backward - must be complete too)
+        _side_stream(dev).wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(_side_stream(dev)):
             check(L().ymi_wgrad_reduce_batch(arr, n, ptr(tab), stream_ptr()), "wgrad_reduce_batch")
         _async["pending"] = True
@@ -799,9 +801,11 @@ def conv_bn_act(x, weight, bn, stride, act=ACT_SILU, residual=None, slot=None):
 
 
 class _FirstConvBnAct(torch.autograd.Function):
-    """The model's first Conv block on the caller's float32 NCHW image (reference yolov8.yaml:738 through conv.py:50-79): direct 3x3
-    stride-2 convolution (csrc/first_conv.hip) that reads the NCHW planes itself and leaves the NHWC bfloat16 copy of the image the
-    backward pass needs as a by-product - no layout pass, no K padding from 27 to 72.  The image receives no gradient."""
+    """The model's first Conv block on the caller's float32 NCHW image (reference yolov8.yaml:738 through conv.py:50-79) as direct
+    kernels that never store the raw convolution output (csrc/first_conv.hip): forward = statistics pass, finalize, apply pass;
+    backward = reduce pass, final sums, fused BatchNorm-apply + weight-gradient pass - each recomputes the 27-tap convolution from the
+    NHWC bfloat16 4-channel copy of the image that the statistics pass leaves behind (26 MB saved for backward instead of a 52 MB
+    padded copy + the 210 MB raw output).  The image receives no gradient."""
 
     @staticmethod
     def forward(ctx, img, weight, gamma, beta, running_mean, running_var, eps, momentum, act):
@@ -811,42 +815,50 @@ class _FirstConvBnAct(torch.autograd.Function):
         dev = img.device
         ho, wo = _conv_out_hw(h, w, 3, 2)
         _note_use(weight)
-        x8 = empty_nhwc(n, 8, h, w, dt, dev)
-        raw = empty_nhwc(n, o, ho, wo, dt, dev)
+        x4 = torch.empty((n, h, w, 4), dtype=dt, device=dev).permute(0, 3, 1, 2)
         out = empty_nhwc(n, o, ho, wo, dt, dev)
         stats = torch.empty((2, o), dtype=torch.float32, device=dev)
         need = (2 * o + (L().ymi_first_conv_stat_blocks(n, h, w) + 64) * 2 * o) * 4
         ws = workspace(need, dev, "conv")
         check(
             L().ymi_first_conv_bn_act_fwd(ptr(img), n, c, h, w, ptr(weight.detach()), o, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), momentum, eps,
-                                          act, _byref(as_ymi(x8)), _byref(as_ymi(raw)), _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(),
-                                          stream_ptr()),
+                                          act, _byref(as_ymi(x4)), _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream_ptr()),
             "first_conv_bn_act_fwd",
         )
-        ctx.save_for_backward(x8, weight, gamma, beta, raw, stats)
+        ctx.save_for_backward(x4, weight, gamma, beta, stats)
         ctx.act = act
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        x8, weight, gamma, beta, raw, stats = ctx.saved_tensors
-        dtype = x8.dtype
+        x4, weight, gamma, beta, stats = ctx.saved_tensors
         o, cin, k, _ = weight.shape
-        dev = x8.device
-        dout = grad_nhwc(dout, dtype)
-        draw = empty_nhwc(*raw.shape, dtype, dev)
+        dev = x4.device
+        dout = grad_nhwc(dout, torch.bfloat16)
         dgamma = torch.empty(o, dtype=torch.float32, device=dev)
         dbeta = torch.empty(o, dtype=torch.float32, device=dev)
-        ws = workspace(2048 * 2 * o * 4 + 256, dev, "bnbwd")
+        n, _, h, w = x4.shape
+        need = int(L().ymi_first_conv_bwd_workspace(n, h, w, o))
+        defer = (ctx.needs_input_grad[1] and _deferred["on"] and _in_backward() and _adoptable((weight,)) and not _deferred_twice((weight,)))
+        dw = _new_dw(o, cin, k, dev, (weight,), None)
+        # (the slabs live in the workspace: a deferred sum needs it alive until the end-of-pass flush)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev) if defer else workspace(need, dev, "firstconv")
+        rec = _lib.WgradPending() if defer else None
         check(
-            L().ymi_bn_act_bwd(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), ptr(beta), ctx.act,
-                               _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()),
-            "bn_act_bwd",
+            L().ymi_first_conv_bn_act_bwd(_byref(as_ymi(x4)), ptr(weight.detach()), cin, o, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ctx.act,
+                                          _byref(as_ymi(dout)), ptr(dgamma), ptr(dbeta), ptr(dw), ptr(ws), ws.numel(), _byref(rec) if defer else None, stream_ptr()),
+            "first_conv_bn_act_bwd",
         )
-        dw = None
-        if ctx.needs_input_grad[1]:
-            dw, _ = _wgrad_maybe_async(x8, draw, o, cin, k, 2, False, (weight,))
-        return None, dw, dgamma, dbeta, None, None, None, None, None
+        if defer:
+            task = torch._C._current_graph_task_id()
+            if _deferred["task"] != task:
+                _deferred["records"], _deferred["keep"], _deferred["owners"] = [], [], []
+                torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
+                _deferred["task"] = task
+            _deferred["records"].append(rec)
+            _deferred["keep"].append((ws, x4, dout))
+            _deferred["owners"].append(weight)
+        return None, (dw if ctx.needs_input_grad[1] else None), dgamma, dbeta, None, None, None, None, None
 
 
 def first_conv_ok(x, conv, residual, slot):

@@ -163,16 +163,6 @@ int ymi_conv2d_bn_silu_fwd_pair(const ymi_tensor* x, const void* w_packed, int64
 int ymi_bn_act_bwd_pair(const ymi_tensor* dout, const ymi_tensor* raw, const float* gamma, const float* beta, const float* gamma2,
                         const float* beta2, int64_t split, const float* save_mean, const float* save_invstd, int32_t act,
                         const ymi_tensor* draw, float* dgamma, float* dbeta, void* workspace, size_t workspace_bytes, void* stream);
-/* The model's FIRST Conv block on the float32 NCHW image the caller hands over (cfg/models/v8/yolov8.yaml:738 `Conv [64, 3, 2]` through
- * nn/modules/conv.py:50-79): act(BatchNorm_train(conv 3x3, stride 2, pad 1)) as a DIRECT kernel that reads the NCHW planes itself (no layout
- * pass, no zero-padded K axis) + finalize + affine/activation.  c <= 4, cout in {16, 32, 48, 64}, bfloat16 outputs.  x8 (may be NULL):
- * receives the NHWC bfloat16 copy of the image, channels zero-padded to 8 - the operand of ymi_conv2d_bwd_weight in the backward pass.
- * workspace >= (2 * cout + (ymi_first_conv_stat_blocks(n, h, w) + 64) * 2 * cout) * 4 bytes. */
-int64_t ymi_first_conv_stat_blocks(int64_t n, int64_t h, int64_t w);
-int ymi_first_conv_bn_act_fwd(const float* img_nchw, int64_t n, int64_t c, int64_t h, int64_t w, const float* weight_oihw, int64_t cout,
-                              const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
-                              int32_t act, const ymi_tensor* x8, const ymi_tensor* raw, const ymi_tensor* out, float* save_mean,
-                              float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
 /* dx = conv_transpose(dy, w): operand packed by ymi_pack_conv_weight_dgrad.  Adjoint of conv.py:79. */
 int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
                         const ymi_tensor* dx, void* stream);
@@ -209,6 +199,26 @@ int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_tensor* dy, in
 /* host_records: the n records of the pending layers (HOST memory; first_block is filled in here); device_table: device
  * scratch for n records.  The records reach the device inside kernel arguments (no host staging: graph-capturable). */
 int ymi_wgrad_reduce_batch(const ymi_wgrad_pending* host_records, int32_t n, ymi_wgrad_pending* device_table, void* stream);
+
+/* The model's FIRST Conv block on the float32 NCHW image the caller hands over (cfg/models/v8/yolov8.yaml:738 `Conv [64, 3, 2]` through
+ * nn/modules/conv.py:50-79): act(BatchNorm_train(conv 3x3, stride 2, pad 1)) as DIRECT kernels that never store the raw convolution output
+ * (27 products per output: recomputing is cheaper than reading back; csrc/first_conv.hip).  c <= 4, cout in {16, 32, 48, 64}, h even,
+ * w % 4 == 0, bfloat16 outputs.
+ *   forward : statistics pass over the image, finalize (running statistics updated), apply pass -> out.  x4 receives the image as NHWC
+ *             bfloat16 [n, 4, h, w] (dense) - all the backward pass needs of the input.
+ *             workspace >= (2 * cout + (ymi_first_conv_stat_blocks(n, h, w) + 64) * 2 * cout) * 4 bytes.
+ *   backward: dgamma, dbeta [cout] and the weight gradient dw_oihw [cout, c, 3, 3] (the image receives none).  pending == NULL: dw is summed
+ *             before the call returns control of the stream; else the slab sum is left to ymi_wgrad_reduce_batch (record in *pending).
+ *             workspace >= ymi_first_conv_bwd_workspace bytes. */
+int64_t ymi_first_conv_stat_blocks(int64_t n, int64_t h, int64_t w);
+int ymi_first_conv_bn_act_fwd(const float* img_nchw, int64_t n, int64_t c, int64_t h, int64_t w, const float* weight_oihw, int64_t cout,
+                              const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum, float eps,
+                              int32_t act, const ymi_tensor* x4, const ymi_tensor* out, float* save_mean, float* save_invstd,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int64_t ymi_first_conv_bwd_workspace(int64_t n, int64_t h, int64_t w, int64_t cout);
+int ymi_first_conv_bn_act_bwd(const ymi_tensor* x4, const float* weight_oihw, int64_t c, int64_t cout, const float* gamma, const float* beta,
+                              const float* save_mean, const float* save_invstd, int32_t act, const ymi_tensor* dout, float* dgamma, float* dbeta,
+                              float* dw_oihw, void* workspace, size_t workspace_bytes, ymi_wgrad_pending* pending, void* stream);
 
 /* -------------------------------------------------------------------- SPPF pooling cascade ---- */
 
