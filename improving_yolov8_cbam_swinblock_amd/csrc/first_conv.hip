@@ -34,7 +34,7 @@ constexpr int FC_PR = 2 * FC_TH + 1;                   // patch rows
 constexpr int FC_ROWB = (2 * FC_TW + 2) * 8;           // bytes per patch row: 8 bytes per pixel; col 0 unused, col 1 = left halo, cols 2.. = the tile's 2 TW columns
                                                        // (so that the aligned groups of the interior start on 16-byte boundaries)
 #ifndef YMI_FC_WG_TILES
-#define YMI_FC_WG_TILES 8
+#define YMI_FC_WG_TILES 4
 #endif
 constexpr int FC_WG_TILES = YMI_FC_WG_TILES;           // tiles per workgroup of the weight-gradient kernel (one slab per workgroup)
 
