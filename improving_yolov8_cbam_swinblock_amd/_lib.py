@@ -64,6 +64,9 @@ _SIGNATURES = {
     "ymi_pack_matrix": (_c_i32, [_vp, _c_i64, _c_i64, _c_i32, _c_i32, _vp, _vp]),
     "ymi_conv2d_fwd": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _c_i32, _TP, _TP, _vp, ctypes.POINTER(_c_i64), _vp]),
     "ymi_conv2d_stat_blocks": (_c_i64, [_c_i64, _c_i64]),
+    "ymi_conv2d_fwd_multi": (_c_i32, [_vp, _c_i32, _vp]),
+    "ymi_conv2d_bwd_data_multi": (_c_i32, [_vp, _c_i32, _vp]),
+    "ymi_bn_finalize_pair": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _vp, _vp, _vp, _vp, _vp]),
     "ymi_bn_finalize": (_c_i32, [_vp, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _vp, _vp, _vp, _vp, _vp]),
     "ymi_scale_shift_act": (_c_i32, [_TP, _vp, _vp, _c_i32, _TP, _TP, _vp]),
     "ymi_conv2d_bn_silu_fwd": (
@@ -117,6 +120,16 @@ _SIGNATURES = {
 }
 
 OPT_MAX_GRADS = 448  # YMI_OPT_MAX_GRADS
+
+
+class ConvProblem(ctypes.Structure):  # ymi_conv_problem
+    _fields_ = [("x", _TP), ("w_packed", _vp), ("cout", _c_i64), ("kh", _c_i64), ("kw", _c_i64), ("stride", _c_i64), ("scale", _vp), ("bias", _vp),
+                ("act", _c_i32), ("_pad", _c_i32), ("residual", _TP), ("y", _TP), ("stat_partials", _vp), ("stat_blocks", _c_i64), ("stat_stride", _c_i64),
+                ("stat_offset", _c_i64)]
+
+
+class DgradProblem(ctypes.Structure):  # ymi_dgrad_problem
+    _fields_ = [("dy", _TP), ("w_dgrad_packed", _vp), ("cin", _c_i64), ("k", _c_i64), ("add1", _TP), ("add2", _TP), ("dx", _TP)]
 
 
 class WgradPending(ctypes.Structure):

@@ -421,6 +421,12 @@ extern "C" int ymi_bn_finalize(const float* part, int64_t blocks, int64_t count,
                                float* sinv, void* stream) {
     return bn_finalize_impl(part, blocks, count, c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv, BnParams2{nullptr, nullptr, nullptr, nullptr, 0}, stream);
 }
+extern "C" int ymi_bn_finalize_pair(const float* part, int64_t blocks, int64_t count, int64_t c, int64_t split, const float* gamma, const float* beta,
+                                    float* rmean, float* rvar, const float* gamma2, const float* beta2, float* rmean2, float* rvar2, float momentum,
+                                    float eps, float* scale, float* shift, float* smean, float* sinv, void* stream) {
+    YMI_CHECK_ARG(split > 0 && split < c && gamma2 && beta2, "bn_finalize_pair: split");
+    return bn_finalize_impl(part, blocks, count, c, gamma, beta, rmean, rvar, momentum, eps, scale, shift, smean, sinv, BnParams2{gamma2, beta2, rmean2, rvar2, (int)split}, stream);
+}
 static int bn_finalize_impl(const float* part, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
                             float* rmean, float* rvar, float momentum, float eps, float* scale, float* shift, float* smean,
                             float* sinv, BnParams2 p2, void* stream) {

@@ -82,6 +82,8 @@ struct IgemmArgs {
     const float* scale;
     const float* bias;
     float* partials;
+    int pstride, poff;     // statistics rows: [M block][2][pstride] floats, this problem's channels at column poff (several problems of one
+                           // BatchNorm group - the two branches of a Detect level - fill one row array side by side); 0, 0: [2][Cout]
     const void* zero;
     int64_t ldx, ldy, ldres, ldres2, ktot;
     int M, H, W, Ho, Wo, Hy, Wy;
@@ -94,11 +96,18 @@ struct IgemmArgs {
     int span;                                 // rows of M an XCD owns: ymi_xcd_span(M) (common.h, XCD ownership of the pixel axis)
 };
 
-// Up to four problems in one launch (the four output-parity classes of a stride-2 data gradient): consecutive ids of an
-// XCD walk the classes of one M block back to back, so the dY rows they all read enter that XCD's L2 once.
+// Several problems in one launch.
+//  * interleaved (hetero == 0; the four output-parity classes of a stride-2 data gradient: same N blocks, same rows read): consecutive
+//    ids of an XCD walk the classes of one M block back to back, so the dY rows they all read enter that XCD's L2 once;
+//  * one after another (hetero == 1; independent convolutions of any shapes that share only the tile form and the channel-chunk
+//    geometry - the same stage of Detect's three levels, reference head.py:66-74): an XCD's id sequence runs through problem 0's tiles,
+//    then problem 1's, ...; each problem keeps its own XCD ownership of ITS pixel order.  Small problems (the 20 x 20 level: 100 tiles)
+//    fill the partial last round of the large ones instead of paying a launch of their own.
+constexpr int IGEMM_MAX_PROBLEMS = 8;
 struct IgemmMulti {
-    IgemmArgs c[4];
+    IgemmArgs c[IGEMM_MAX_PROBLEMS];
     int ncls;
+    int hetero;
 };
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -380,7 +389,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
             for (int q = 0; q < WM; ++q) sum += red[(q * 2 + which) * BN + chl];
             const int ch = n0 + chl;
-            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.Cout + ch] = sum;
+            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.pstride + a.poff + ch] = sum;
         }
     }
     if (a.vec16) {
@@ -534,7 +543,24 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
     // GEMM's epilogue) wrote that eighth from this XCD too, so they are in this L2, not in another one's.
     // The 1-D grid is padded to 8 * mpx * nnb ids; ids that fall outside the XCD's range leave before any barrier.
     const int orig = blockIdx.x, xcd = orig & 7, seq0 = orig >> 3;
-    const int cls = P.ncls > 1 ? seq0 % P.ncls : 0, seq = P.ncls > 1 ? seq0 / P.ncls : seq0;  // block-uniform
+    int cls = 0, seq = seq0;  // block-uniform
+    if (P.hetero) {
+        // problems one after another: skip the tiles this XCD owns of problems 0 .. cls-1 (scalar arithmetic on kernel arguments)
+#pragma unroll 1
+        for (; cls < P.ncls; ++cls) {
+            const int sp = P.c[cls].span, nmbc = P.c[cls].nmb;
+            const int f = (xcd * sp + BM - 1) / BM;
+            int l = ((xcd + 1) * sp + BM - 1) / BM;
+            l = l < nmbc ? l : nmbc;
+            const int cnt = (l > f ? l - f : 0) * P.c[cls].nnb;
+            if (seq < cnt) break;
+            seq -= cnt;
+        }
+        if (cls >= P.ncls) return;  // grid padding
+    } else if (P.ncls > 1) {
+        cls = seq0 % P.ncls;
+        seq = seq0 / P.ncls;
+    }
     const IgemmArgs a = P.c[cls];
     const int nb = seq % a.nnb, ml = seq / a.nnb;
     // this XCD owns the M blocks whose first row lies in its span of the pixel order (the rule every streaming kernel follows, common.h)
@@ -890,9 +916,11 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool bf16) 
 // instruction then touches 8 full 128-byte cache lines instead of 16 half lines, and there is one barrier per
 // 32 MFMAs per wave instead of per 16.
 template <typename T, bool STATS>
-static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStream_t stream) {
+static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStream_t stream, bool hetero = false) {
     IgemmMulti P{};
     P.ncls = ncls;
+    P.hetero = hetero ? 1 : 0;
+    int64_t per_xcd[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // hetero: tiles each XCD runs, over all problems
     int mpx = 0;
     for (int i = 0; i < ncls; ++i) {
         P.c[i] = arr[i];
@@ -906,11 +934,17 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
             int64_t last = ((x + 1) * span + t.bm - 1) / t.bm;
             if (last > P.c[i].nmb) last = P.c[i].nmb;
             if (last - first > mpx) mpx = (int)(last - first);
+            if (last > first) per_xcd[x] += (last - first) * P.c[i].nnb;
         }
     }
-    for (int i = 0; i < ncls; ++i) P.c[i].mpx = mpx;  // one id decode for all classes (same Cout => same nnb)
+    for (int i = 0; i < ncls; ++i) P.c[i].mpx = mpx;  // interleaved form: one id decode for all classes (same Cout => same nnb)
     const IgemmArgs& a = P.c[0];
     dim3 grid((unsigned)(8 * mpx * a.nnb * ncls));
+    if (hetero) {
+        int64_t mx = 0;
+        for (int x = 0; x < 8; ++x) mx = per_xcd[x] > mx ? per_xcd[x] : mx;
+        grid = dim3((unsigned)(8 * mx));
+    }
     const bool fast = (a.cpt % 4) == 0;
     const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0;
     size_t lds = (size_t)2 * (t.bm + t.bn) * (wide ? 128 : 64);
@@ -967,16 +1001,28 @@ bool ymi_prof_enabled();
 int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, double peak_tflops);
 void ymi_prof_stop(hipStream_t stream, int idx);
 
-// ncls problems (same dtype, Cout, channel geometry) in one launch; statistics mode only for a single problem
-static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats, int* host_blocks, hipStream_t stream) {
-    int64_t mmax = 0;
+// ncls problems in one launch.  hetero == false: same dtype, Cout, channel geometry (the interleaved form: parity classes of a stride-2
+// data gradient).  hetero == true: any shapes, one after another; they must agree on dtype and on the K-chunk form (all with input
+// channels in whole K steps, of the same width class) - checked here.  host_blocks: ncls entries (statistics rows per problem).
+static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats, int* host_blocks, hipStream_t stream, bool hetero = false) {
+    YMI_CHECK_ARG(ncls >= 1 && ncls <= IGEMM_MAX_PROBLEMS, "igemm: %d problems in one launch (at most %d)", ncls, IGEMM_MAX_PROBLEMS);
+    int64_t mmax = 0, msum = 0;
     int64_t kmax = 0;
+    int cmax = 0, cmin = 1 << 30;
     for (int i = 0; i < ncls; ++i) {
         mmax = arr[i].M > mmax ? arr[i].M : mmax;
+        msum += arr[i].M;
         kmax = arr[i].ktot > kmax ? arr[i].ktot : kmax;
+        cmax = arr[i].Cout > cmax ? arr[i].Cout : cmax;
+        cmin = arr[i].Cout < cmin ? arr[i].Cout : cmin;
+        if (hetero) YMI_CHECK_ARG((arr[i].cpt % 4 == 0) == (arr[0].cpt % 4 == 0) && (arr[i].cpt % 8 == 0) == (arr[0].cpt % 8 == 0),
+                                  "igemm: the problems of one launch must share the K-chunk form (input channels in whole K steps)");
     }
-    TileChoice t = choose_tile(mmax * ncls, arr[0].Cout, kmax, dtype == YMI_BF16);
-    if (host_blocks) *host_blocks = (arr[0].M + t.bm - 1) / t.bm;
+    // one tile form for the launch: chosen for the widest problem over all the rows (a narrower problem pads its N block)
+    TileChoice t = hetero ? choose_tile(msum, cmax, kmax, dtype == YMI_BF16) : choose_tile(mmax * ncls, arr[0].Cout, kmax, dtype == YMI_BF16);
+    if (hetero && t.bn > 64 && cmin <= 64 && cmax > 64 && !t.pp) t.bn = 64;  // (mixed widths: 64-column tiles waste nothing on the narrow ones)
+    if (host_blocks)
+        for (int i = 0; i < (hetero ? ncls : 1); ++i) host_blocks[i] = (arr[i].M + t.bm - 1) / t.bm;
     int prof = -1;
     if (ymi_prof_enabled()) {
         const double es = dtype == YMI_BF16 ? 2.0 : 4.0;
@@ -986,13 +1032,15 @@ static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats,
             flop += 2.0 * (double)a.M * (double)a.Cout * (double)a.ktot;
             bytes += (double)a.ktot * a.Cout * es + (double)a.M * a.Cout * es * (a.res ? 2.0 : 1.0);
         }
-        const IgemmArgs& a0 = arr[0];
-        bytes += (double)a0.M / ((double)a0.Ho * a0.Wo) * (double)a0.H * a0.W * a0.cpt * 16.0;  // the whole input map, read once
+        for (int i = 0; i < (hetero ? ncls : 1); ++i) {
+            const IgemmArgs& a0 = arr[i];
+            bytes += (double)a0.M / ((double)a0.Ho * a0.Wo) * (double)a0.H * a0.W * a0.cpt * 16.0;  // the whole input map, read once
+        }
         prof = ymi_prof_start(stream, 0, flop, bytes, dtype == YMI_BF16 ? 2500.0 : 157.3);
     }
     int rc;
-    if (dtype == YMI_BF16) rc = stats ? launch_igemm_t<bf16_t, true>(arr, ncls, t, stream) : launch_igemm_t<bf16_t, false>(arr, ncls, t, stream);
-    else rc = stats ? launch_igemm_t<float, true>(arr, ncls, t, stream) : launch_igemm_t<float, false>(arr, ncls, t, stream);
+    if (dtype == YMI_BF16) rc = stats ? launch_igemm_t<bf16_t, true>(arr, ncls, t, stream, hetero) : launch_igemm_t<bf16_t, false>(arr, ncls, t, stream, hetero);
+    else rc = stats ? launch_igemm_t<float, true>(arr, ncls, t, stream, hetero) : launch_igemm_t<float, false>(arr, ncls, t, stream, hetero);
     ymi_prof_stop(stream, prof);
     return rc;
 }
@@ -1034,9 +1082,23 @@ extern "C" int64_t ymi_conv2d_stat_blocks(int64_t m_rows, int64_t cout) {
     return (m_rows + 63) / 64 + 64;  // smallest BM any tile choice uses, + the 64 staging rows ymi_bn_finalize may append
 }
 
+static int conv_fwd_args(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                         const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
+                         const ymi_tensor* y2, int32_t act2, float* stat_partials, IgemmArgs* out);
 static int conv_fwd_impl(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
                          const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
                          const ymi_tensor* y2, int32_t act2, float* stat_partials, int64_t* host_stat_blocks, void* stream) {
+    IgemmArgs a{};
+    int rc = conv_fwd_args(x, w_packed, cout, kh, kw, stride, scale, bias, act, residual, y, y2, act2, stat_partials, &a);
+    if (rc) return rc;
+    int blocks = 0;
+    rc = ymi_launch_igemm(a, x->dtype, stat_partials != nullptr, &blocks, (hipStream_t)stream);
+    if (host_stat_blocks) *host_stat_blocks = blocks;
+    return rc;
+}
+static int conv_fwd_args(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                         const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
+                         const ymi_tensor* y2, int32_t act2, float* stat_partials, IgemmArgs* out) {
     YMI_CHECK_ARG(ymi_tensor_ok(x) && ymi_tensor_ok(y) && w_packed, "conv2d_fwd: bad tensor");
     if (y2) {
         YMI_CHECK_ARG(ymi_tensor_ok(y2) && ymi_same_shape(y2, y) && y2->dtype == y->dtype && !stat_partials, "conv2d_fwd: second output");
@@ -1061,6 +1123,7 @@ static int conv_fwd_impl(const ymi_tensor* x, const void* w_packed, int64_t cout
     IgemmArgs a{};
     a.x = x->data; a.w = w_packed; a.y = y->data; a.res = residual ? residual->data : nullptr;
     a.scale = scale; a.bias = bias; a.partials = stat_partials; a.zero = ymi_zero_page();
+    a.pstride = (int)cout; a.poff = 0;
     a.ldx = x->ld; a.ldy = y->ld; a.ldres = residual ? residual->ld : 0;
     a.M = (int)(x->n * ho * wo); a.H = (int)x->h; a.W = (int)x->w; a.Ho = (int)ho; a.Wo = (int)wo; a.Hy = (int)ho; a.Wy = (int)wo;
     a.s_in = (int)stride; a.s_out = 1; a.oh_off = 0; a.ow_off = 0;
@@ -1075,10 +1138,33 @@ static int conv_fwd_impl(const ymi_tensor* x, const void* w_packed, int64_t cout
     a.vec_store = (y->ld % g == 0) && (((uintptr_t)y->data) % (g * ymi_esize(y->dtype)) == 0) &&
                   (!residual || (residual->ld % g == 0 && ((uintptr_t)residual->data) % (g * ymi_esize(y->dtype)) == 0));
     finish_args(a, y, residual);
-    int blocks = 0;
-    int rc = ymi_launch_igemm(a, x->dtype, stat_partials != nullptr, &blocks, (hipStream_t)stream);
-    if (host_stat_blocks) *host_stat_blocks = blocks;
-    return rc;
+    *out = a;
+    return YMI_OK;
+}
+
+// Several independent convolutions in ONE launch (problems one after another: IgemmMulti, hetero form) - the same stage of Detect's three
+// levels (reference nn/modules/head.py:66-74 runs them in a Python loop), whose 40 x 40 and 20 x 20 levels are too small to fill the chip
+// on their own.  All problems: the same dtype, statistics mode for all or none, input channels in whole K steps of the same width class.
+extern "C" int ymi_conv2d_fwd_multi(const ymi_conv_problem* problems, int32_t n, void* stream) {
+    YMI_CHECK_ARG(problems && n >= 1 && n <= IGEMM_MAX_PROBLEMS, "conv2d_fwd_multi: 1..%d problems", IGEMM_MAX_PROBLEMS);
+    IgemmArgs arr[IGEMM_MAX_PROBLEMS];
+    int blocks[IGEMM_MAX_PROBLEMS];
+    const bool stats = problems[0].stat_partials != nullptr;
+    for (int i = 0; i < n; ++i) {
+        const ymi_conv_problem& p = problems[i];
+        YMI_CHECK_ARG(p.x && p.y && p.x->dtype == problems[0].x->dtype && (p.stat_partials != nullptr) == stats, "conv2d_fwd_multi: problem %d: dtype / statistics mode differ", i);
+        int rc = conv_fwd_args(p.x, p.w_packed, p.cout, p.kh, p.kw, p.stride, p.scale, p.bias, p.act, p.residual, p.y, nullptr, YMI_ACT_NONE, p.stat_partials, &arr[i]);
+        if (rc) return rc;
+        if (p.stat_stride > 0) {
+            YMI_CHECK_ARG(p.stat_offset >= 0 && p.stat_offset + p.cout <= p.stat_stride, "conv2d_fwd_multi: problem %d: statistics columns", i);
+            arr[i].pstride = (int)p.stat_stride;
+            arr[i].poff = (int)p.stat_offset;
+        }
+    }
+    int rc = launch_igemm_n(arr, n, problems[0].x->dtype, stats, blocks, (hipStream_t)stream, true);
+    if (rc) return rc;
+    for (int i = 0; i < n; ++i) const_cast<ymi_conv_problem*>(problems)[i].stat_blocks = blocks[i];
+    return YMI_OK;
 }
 
 extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
@@ -1178,6 +1264,51 @@ static int dgrad_impl(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t 
         if (rc) return rc;
     }
     return YMI_OK;
+}
+
+// Several independent stride-1 data gradients in one launch (ymi_conv2d_fwd_multi's counterpart; each problem may carry its epilogue addends).
+static int dgrad_args_s1(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t k, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, IgemmArgs* out) {
+    YMI_CHECK_ARG(ymi_tensor_ok(dy) && ymi_tensor_ok(dx) && w_dgrad_packed, "conv2d_bwd_data_multi: bad tensor");
+    if (add1 || add2) {
+        YMI_CHECK_ARG(add1 && ymi_tensor_ok(add1) && ymi_same_shape(add1, dx) && add1->dtype == dx->dtype, "conv2d_bwd_data_multi: first addend");
+        YMI_CHECK_ARG(!add2 || (ymi_tensor_ok(add2) && ymi_same_shape(add2, dx) && add2->dtype == dx->dtype), "conv2d_bwd_data_multi: second addend");
+    }
+    YMI_CHECK_ARG(dy->dtype == dx->dtype, "conv2d_bwd_data_multi: dtype mismatch");
+    const int ch = dy->dtype == YMI_BF16 ? 8 : 4;
+    YMI_CHECK_ARG(dy->c % ch == 0 && dy->ld % ch == 0 && (k == 1 || k == 3), "conv2d_bwd_data_multi: dy channels in whole chunks, k in {1, 3}");
+    YMI_CHECK_ARG(dx->c == cin && dx->n == dy->n && dy->h == dx->h && dy->w == dx->w, "conv2d_bwd_data_multi: shapes (stride 1)");
+    YMI_CHECK_ARG(ymi_pixels(dx) * dx->ld < (1ll << 31) && ymi_pixels(dy) * dy->ld < (1ll << 31), "conv2d_bwd_data_multi: too large");
+    const size_t es = ymi_esize(dy->dtype);
+    const int pad = (int)k / 2;
+    int dh[9], dw[9], nt = 0;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j) { dh[nt] = pad - i; dw[nt] = pad - j; ++nt; }
+    IgemmArgs a{};
+    a.x = dy->data; a.w = w_dgrad_packed; a.y = dx->data; a.zero = ymi_zero_page();
+    a.ldx = dy->ld; a.ldy = dx->ld;
+    a.res = add1 ? add1->data : nullptr; a.ldres = add1 ? add1->ld : 0;
+    a.res2 = add2 ? add2->data : nullptr; a.ldres2 = add2 ? add2->ld : 0;
+    a.M = (int)ymi_pixels(dx); a.H = (int)dy->h; a.W = (int)dy->w; a.Ho = (int)dx->h; a.Wo = (int)dx->w; a.Hy = (int)dx->h; a.Wy = (int)dx->w;
+    a.s_in = 1; a.s_out = 1; a.oh_off = 0; a.ow_off = 0;
+    a.Cout = (int)cin; a.cpt = (int)(dy->c / ch); a.ntaps = nt; a.KC = nt * a.cpt; a.ktot = (int64_t)a.KC * ch;
+    pack_taps(dh, dw, nt, &a.tap_dh, &a.tap_dw);
+    a.act = YMI_ACT_NONE;
+    a.vec_store = (dx->ld % 4 == 0) && (((uintptr_t)dx->data) % (4 * es) == 0) && (!add1 || (add1->ld % 4 == 0 && ((uintptr_t)add1->data) % (4 * es) == 0)) &&
+                  (!add2 || (add2->ld % 4 == 0 && ((uintptr_t)add2->data) % (4 * es) == 0));
+    finish_args(a, dx, nullptr);
+    *out = a;
+    return YMI_OK;
+}
+extern "C" int ymi_conv2d_bwd_data_multi(const ymi_dgrad_problem* problems, int32_t n, void* stream) {
+    YMI_CHECK_ARG(problems && n >= 1 && n <= IGEMM_MAX_PROBLEMS, "conv2d_bwd_data_multi: 1..%d problems", IGEMM_MAX_PROBLEMS);
+    IgemmArgs arr[IGEMM_MAX_PROBLEMS];
+    for (int i = 0; i < n; ++i) {
+        const ymi_dgrad_problem& p = problems[i];
+        YMI_CHECK_ARG(p.dy && p.dx && p.dy->dtype == problems[0].dy->dtype, "conv2d_bwd_data_multi: problem %d", i);
+        int rc = dgrad_args_s1(p.dy, p.w_dgrad_packed, p.cin, p.k, p.add1, p.add2, p.dx, &arr[i]);
+        if (rc) return rc;
+    }
+    return launch_igemm_n(arr, n, problems[0].dy->dtype, false, nullptr, (hipStream_t)stream, true);
 }
 
 // ---- SwinBlock MLP (swin_block.py:33,53: Linear(C, 4C) -> GELU -> Linear(4C, C), + the skip) ------------------------------------

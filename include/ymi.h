@@ -124,6 +124,24 @@ int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int6
                    const float* scale, const float* bias, int32_t act, const ymi_tensor* residual, const ymi_tensor* y,
                    float* stat_partials, int64_t* host_stat_blocks, void* stream);
 int64_t ymi_conv2d_stat_blocks(int64_t m_rows, int64_t cout);
+/* Several independent convolutions (any shapes; same dtype; statistics mode for all or none; input channels in whole K steps of the same
+ * width class; with statistics: the same output-pixel count per BatchNorm group) in ONE launch, at most 8: the same stage of Detect's three levels (nn/modules/head.py:66-74 loops over them), whose small
+ * levels cannot fill the chip alone.  Arguments per problem as ymi_conv2d_fwd; stat_blocks is written by the call. */
+typedef struct ymi_conv_problem {
+    const ymi_tensor* x;
+    const void* w_packed;
+    int64_t cout, kh, kw, stride;
+    const float* scale;
+    const float* bias;
+    int32_t act, _pad;
+    const ymi_tensor* residual;
+    const ymi_tensor* y;
+    float* stat_partials;
+    int64_t stat_blocks;
+    int64_t stat_stride, stat_offset; /* statistics rows [block][2][stat_stride] with this problem's channels at column stat_offset: the problems of
+                                       * one BatchNorm group share a row array (all problems of a launch use the same row tile); 0: [2][cout] */
+} ymi_conv_problem;
+int ymi_conv2d_fwd_multi(const ymi_conv_problem* problems, int32_t n, void* stream);
 
 /* Train-mode BatchNorm2d statistics from the partials above (nn/modules/conv.py:66,79 with
  * eps/momentum of utils/torch_utils.py:468-470): writes scale = gamma*invstd, shift = beta - mean*scale,
@@ -131,6 +149,11 @@ int64_t ymi_conv2d_stat_blocks(int64_t m_rows, int64_t cout);
 int ymi_bn_finalize(const float* stat_partials, int64_t blocks, int64_t count, int64_t c, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps, float* scale, float* shift,
                     float* save_mean, float* save_invstd, void* stream);
+/* the same for two BatchNorms whose channels lie side by side (channels >= split read gamma2 / beta2 and update running_*2): the
+ * BatchNorms of two convolutions that ran as one, or side by side into one buffer (Detect's branches, head.py:44-59). */
+int ymi_bn_finalize_pair(const float* stat_partials, int64_t blocks, int64_t count, int64_t c, int64_t split, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, const float* gamma2, const float* beta2, float* running_mean2, float* running_var2,
+                         float momentum, float eps, float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 /* out = act(raw*scale[c] + shift[c]) + residual : BN-affine + SiLU (+ Bottleneck add, block.py:488). */
 int ymi_scale_shift_act(const ymi_tensor* raw, const float* scale, const float* shift, int32_t act, const ymi_tensor* residual,
                         const ymi_tensor* out, void* stream);
@@ -173,6 +196,16 @@ int ymi_conv2d_bwd_data(const ymi_tensor* dy, const void* w_dgrad_packed, int64_
  * are left as the caller prepared them (zeros) and addends must be NULL (EINVAL otherwise). */
 int ymi_conv2d_bwd_data_add(const ymi_tensor* dy, const void* w_dgrad_packed, int64_t cin, int64_t kh, int64_t kw, int64_t stride,
                             const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* dx, void* stream);
+/* ... and several independent STRIDE-1 data gradients in one launch (k x k kernel, k in {1, 3}; addends as above). */
+typedef struct ymi_dgrad_problem {
+    const ymi_tensor* dy;
+    const void* w_dgrad_packed;
+    int64_t cin, k;
+    const ymi_tensor* add1;
+    const ymi_tensor* add2;
+    const ymi_tensor* dx;
+} ymi_dgrad_problem;
+int ymi_conv2d_bwd_data_multi(const ymi_dgrad_problem* problems, int32_t n, void* stream);
 /* dw (OIHW f32 [cout_real][cin_real][kh][kw], overwritten) = sum over pixels dy (x) x ; optional
  * dbias = column sums of dy: a buffer of dy->c floats (the PADDED channel count), of which the first cout_real are the bias gradient.  x / dy may carry zero-padded channels (x->c >= cin_real,
  * dy->c >= cout_real).  Split-K MFMA GEMM + ordered slab reduce (deterministic); workspace from
