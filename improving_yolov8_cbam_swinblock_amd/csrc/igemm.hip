@@ -945,8 +945,12 @@ static int launch_igemm_t(const IgemmArgs* arr, int ncls, TileChoice t, hipStrea
         for (int x = 0; x < 8; ++x) mx = per_xcd[x] > mx ? per_xcd[x] : mx;
         grid = dim3((unsigned)(8 * mx));
     }
-    const bool fast = (a.cpt % 4) == 0;
-    const bool wide = std::is_same<T, bf16_t>::value && (a.cpt % 8) == 0;
+    // the K-step form every problem of the launch can run under (8-chunk steps need cpt % 8, whole-step taps cpt % 4; else the general form)
+    bool fast = true, wide = std::is_same<T, bf16_t>::value;
+    for (int i = 0; i < ncls; ++i) {
+        fast = fast && (P.c[i].cpt % 4) == 0;
+        wide = wide && (P.c[i].cpt % 8) == 0;
+    }
     size_t lds = (size_t)2 * (t.bm + t.bn) * (wide ? 128 : 64);
     const size_t epi = (size_t)t.bm * (t.bn * sizeof(T) + 16) + (STATS ? 4 * 2 * t.bn * sizeof(float) : 0);
     if (epi > lds) lds = epi;
@@ -1002,8 +1006,8 @@ int ymi_prof_start(hipStream_t stream, int family, double flop, double bytes, do
 void ymi_prof_stop(hipStream_t stream, int idx);
 
 // ncls problems in one launch.  hetero == false: same dtype, Cout, channel geometry (the interleaved form: parity classes of a stride-2
-// data gradient).  hetero == true: any shapes, one after another; they must agree on dtype and on the K-chunk form (all with input
-// channels in whole K steps, of the same width class) - checked here.  host_blocks: ncls entries (statistics rows per problem).
+// data gradient).  hetero == true: any shapes, one after another; they agree on dtype, and the launch runs in the K-step
+// form ALL of them allow (8-chunk steps only when every problem's input width is a multiple of 64 bf16 channels).  host_blocks: ncls entries (statistics rows per problem).
 static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats, int* host_blocks, hipStream_t stream, bool hetero = false) {
     YMI_CHECK_ARG(ncls >= 1 && ncls <= IGEMM_MAX_PROBLEMS, "igemm: %d problems in one launch (at most %d)", ncls, IGEMM_MAX_PROBLEMS);
     int64_t mmax = 0, msum = 0;
@@ -1015,8 +1019,6 @@ static int launch_igemm_n(const IgemmArgs* arr, int ncls, int dtype, bool stats,
         kmax = arr[i].ktot > kmax ? arr[i].ktot : kmax;
         cmax = arr[i].Cout > cmax ? arr[i].Cout : cmax;
         cmin = arr[i].Cout < cmin ? arr[i].Cout : cmin;
-        if (hetero) YMI_CHECK_ARG((arr[i].cpt % 4 == 0) == (arr[0].cpt % 4 == 0) && (arr[i].cpt % 8 == 0) == (arr[0].cpt % 8 == 0),
-                                  "igemm: the problems of one launch must share the K-chunk form (input channels in whole K steps)");
     }
     // one tile form for the launch: chosen for the widest problem over all the rows (a narrower problem pads its N block)
     TileChoice t = hetero ? choose_tile(msum, cmax, kmax, dtype == YMI_BF16) : choose_tile(mmax * ncls, arr[0].Cout, kmax, dtype == YMI_BF16);
@@ -1144,7 +1146,7 @@ static int conv_fwd_args(const ymi_tensor* x, const void* w_packed, int64_t cout
 
 // Several independent convolutions in ONE launch (problems one after another: IgemmMulti, hetero form) - the same stage of Detect's three
 // levels (reference nn/modules/head.py:66-74 runs them in a Python loop), whose 40 x 40 and 20 x 20 levels are too small to fill the chip
-// on their own.  All problems: the same dtype, statistics mode for all or none, input channels in whole K steps of the same width class.
+// on their own.  All problems: the same dtype, statistics mode for all or none (callers group problems of like input-width class: a mixed launch runs in the slowest form).
 extern "C" int ymi_conv2d_fwd_multi(const ymi_conv_problem* problems, int32_t n, void* stream) {
     YMI_CHECK_ARG(problems && n >= 1 && n <= IGEMM_MAX_PROBLEMS, "conv2d_fwd_multi: 1..%d problems", IGEMM_MAX_PROBLEMS);
     IgemmArgs arr[IGEMM_MAX_PROBLEMS];

@@ -98,13 +98,25 @@ class Detect(nn.Module):
             return ha, hb
         return self._branch(a, xi), self._branch(b, xi)
 
-    def forward(self, x):
-        x = list(x)
+    def _maps(self, x):
+        """-> ([box map], [class map]) of all levels.  Training: the stages of the three levels in lockstep, one GEMM launch per stage
+        (ops.detect_train) when the branch shapes allow; else level by level as the reference loops (head.py:70-72)."""
+        xs = [ops.to_internal(xi) for xi in x]
+        if self.training and torch.is_grad_enabled() and self.pair_ok:
+            levels = [(a[0], b[0], a[1], b[1], a[2], b[2]) for a, b in zip(self.cv2, self.cv3)]
+            if ops.detect_train_ok(levels, xs[0].dtype) and all(xi.dtype == xs[0].dtype for xi in xs):
+                return ops.detect_train(xs, levels)
         box, cls = [], []
         for i in range(self.nl):
-            bi, ci = self._level(i, ops.to_internal(x[i]))
+            bi, ci = self._level(i, xs[i])
             box.append(bi)
             cls.append(ci)
+        return box, cls
+
+    def forward(self, x):
+        x = list(x)
+        box, cls = self._maps(x)
+        for i in range(self.nl):
             x[i] = ops.concat([box[i], cls[i]])
         if self.training:
             return x
@@ -115,12 +127,7 @@ class Detect(nn.Module):
     def forward_split(self, x):
         """train-mode maps WITHOUT the per-level concat (the loss splits them again, reference loss.py:205-207):
         -> (box list [B, 64, H, W], cls list [B, nc, H, W]).  Used by DetectionModel.loss."""
-        box, cls = [], []
-        for i in range(self.nl):
-            bi, ci = self._level(i, ops.to_internal(x[i]))
-            box.append(bi)
-            cls.append(ci)
-        return box, cls
+        return self._maps(x)
 
     def _inference(self, box, cls=None):
         """reference head.py:103-142, non-export branch: DFL expectation, anchor decode, stride scale and class sigmoid in

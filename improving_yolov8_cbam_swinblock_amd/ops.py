@@ -15,7 +15,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, as_ymi, check, chunk_elems, empty_nhwc, is_nhwc, ptr, stream_ptr, workspace, ymi_dtype
+from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, ConvProblem, DgradProblem, as_ymi, check, chunk_elems, empty_nhwc, is_nhwc, ptr, stream_ptr, workspace, ymi_dtype
 
 _byref = ctypes.byref
 
@@ -633,11 +633,8 @@ def _prep_adds(adds, dtype, like4d):
     return out
 
 
-def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None, packed=None):
-    """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight (+ up to two addends summed in the GEMM's
-    epilogue, further ones by accumulate launches); zero-padded input channels get zero.  out: write the result into this
-    NHWC view (it may be one of the addends: the epilogue reads an addend before it stores the sum).
-    packed: (operand, cin) of an already packed data-gradient operand (weight4 is then unused)."""
+def _dgrad_prepare(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None, packed=None):
+    """the arguments of one data-gradient GEMM (see _dgrad) -> job dict; _dgrad_finish completes it after the launch."""
     n, cp, h, w = in_shape
     ty = as_ymi(dy)
     if packed is not None:
@@ -655,16 +652,91 @@ def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None, packed=
     if sparse and cp == cin:
         dx.zero_()  # (_dgrad_joined never passes an in-place `out` in this case)
     fused = adds[:2] if (cp == cin and not sparse) else []
+    return {"dy": dy, "ty": ty, "wd": wd, "cin": cin, "k": k, "stride": stride, "fused": fused, "rest": adds[len(fused):], "dx": dx, "dxv": dxv}
+
+
+def _dgrad_finish(job):
+    if job["rest"]:
+        _accumulate(job["dxv"], job["rest"])
+    return job["dx"]
+
+
+def _dgrad(dy, weight4, k, stride, in_shape, dtype, adds=None, out=None, packed=None):
+    """dx [N, C_in(padded), H, W] (NHWC) from dy and the OIHW weight (+ up to two addends summed in the GEMM's
+    epilogue, further ones by accumulate launches); zero-padded input channels get zero.  out: write the result into this
+    NHWC view (it may be one of the addends: the epilogue reads an addend before it stores the sum).
+    packed: (operand, cin) of an already packed data-gradient operand (weight4 is then unused)."""
+    return _dgrad_launch(_dgrad_prepare(dy, weight4, k, stride, in_shape, dtype, adds, out, packed))
+
+
+def _dgrad_launch(j):
+    fused = j["fused"]
     a1 = _byref(as_ymi(fused[0])) if len(fused) > 0 else None
     a2 = _byref(as_ymi(fused[1])) if len(fused) > 1 else None
-    check(L().ymi_conv2d_bwd_data_add(_byref(ty), ptr(wd), cin, k, k, stride, a1, a2, _byref(as_ymi(dxv)), stream_ptr()), "conv2d_bwd_data")
-    if len(adds) > len(fused):
-        _accumulate(dxv, adds[len(fused):])
-    return dx
+    check(L().ymi_conv2d_bwd_data_add(_byref(j["ty"]), ptr(j["wd"]), j["cin"], j["k"], j["k"], j["stride"], a1, a2, _byref(as_ymi(j["dxv"])), stream_ptr()),
+          "conv2d_bwd_data")
+    return _dgrad_finish(j)
 
 
-def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype, packed=None):
-    """data gradient of a consumer of a (possibly joined) tensor: deposits (and returns None) unless it is the last consumer."""
+def _width_class(c, dtype):
+    """problems of one multi-problem GEMM launch must agree on this (the K-step form of the kernel: csrc/igemm.hip launch_igemm_n)."""
+    cpt = int(c) // chunk_elems(dtype)
+    return (cpt % 4 == 0, cpt % 8 == 0)
+
+
+def _dgrad_multi(jobs, dtype):
+    """the stride-1 data-gradient GEMMs of several INDEPENDENT convolutions (jobs of _dgrad_prepare), one launch per width class."""
+    groups = {}
+    for j in jobs:
+        if j["stride"] != 1:
+            raise RuntimeError("_dgrad_multi: stride 1 only")
+        groups.setdefault(_width_class(j["ty"].c, dtype), []).append(j)
+    for g in groups.values():
+        for s in range(0, len(g), 8):
+            chunk = g[s : s + 8]
+            arr = (DgradProblem * len(chunk))()
+            keep = []
+            for q, j in zip(arr, chunk):
+                ts = [j["ty"], as_ymi(j["dxv"])] + [as_ymi(a) for a in j["fused"]]
+                keep.append(ts)
+                q.dy, q.dx = ctypes.pointer(ts[0]), ctypes.pointer(ts[1])
+                q.w_dgrad_packed, q.cin, q.k = j["wd"].data_ptr(), j["cin"], j["k"]
+                if len(ts) > 2:
+                    q.add1 = ctypes.pointer(ts[2])
+                if len(ts) > 3:
+                    q.add2 = ctypes.pointer(ts[3])
+            check(L().ymi_conv2d_bwd_data_multi(arr, len(chunk), stream_ptr()), "conv2d_bwd_data_multi")
+    return [_dgrad_finish(j) for j in jobs]
+
+
+def _conv_fwd_multi(problems, dtype):
+    """several INDEPENDENT stride-1 convolutions, one launch per width class.  problems: dicts x, wp, cout, k, y and optionally bias, or
+    part / pstride / poff (statistics rows, see ymi_conv_problem); 'blocks' (statistics rows written) is filled in."""
+    groups = {}
+    for p in problems:
+        groups.setdefault((_width_class(p["x"].shape[1], dtype), p.get("part") is not None), []).append(p)
+    for g in groups.values():
+        for s in range(0, len(g), 8):
+            chunk = g[s : s + 8]
+            arr = (ConvProblem * len(chunk))()
+            keep = []
+            for q, p in zip(arr, chunk):
+                tx, ty = as_ymi(p["x"]), as_ymi(p["y"])
+                keep.append((tx, ty))
+                q.x, q.y = ctypes.pointer(tx), ctypes.pointer(ty)
+                q.w_packed, q.cout, q.kh, q.kw, q.stride, q.act = p["wp"].data_ptr(), p["cout"], p["k"], p["k"], 1, ACT_NONE
+                if p.get("bias") is not None:
+                    q.bias = p["bias"].data_ptr()
+                if p.get("part") is not None:
+                    q.stat_partials, q.stat_stride, q.stat_offset = p["part"].data_ptr(), p.get("pstride", 0), p.get("poff", 0)
+            check(L().ymi_conv2d_fwd_multi(arr, len(chunk), stream_ptr()), "conv2d_fwd_multi")
+            for q, p in zip(arr, chunk):
+                p["blocks"] = int(q.stat_blocks)
+
+
+def _dgrad_joined_prepare(join, dy, weight4, k, stride, in_shape, dtype, packed=None):
+    """-> (job, deposit): the data-gradient GEMM of a consumer of a (possibly joined) tensor, with the join's earlier contributions as
+    addends when this is the last consumer; deposit: the result is a contribution to hand to the join (_dgrad_joined_finish)."""
     adds = join.arrive() if join is not None else []
     out = None
     if adds is not None and join is not None and join.dst is not None:
@@ -679,11 +751,20 @@ def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype, packed=None):
             adds = list(adds) + [out]  # the contribution already in the buffer rides as an addend; the total replaces it
         else:
             out = None  # (left for _C2fSplit's own add)
-    dx = _dgrad(dy, weight4, k, stride, in_shape, dtype, adds, out, packed)
-    if adds is None:
+    return _dgrad_prepare(dy, weight4, k, stride, in_shape, dtype, adds, out, packed), adds is None
+
+
+def _dgrad_joined_finish(join, dx, deposit):
+    if deposit:
         join.deposit(dx)
         return None
     return dx
+
+
+def _dgrad_joined(join, dy, weight4, k, stride, in_shape, dtype, packed=None):
+    """data gradient of a consumer of a (possibly joined) tensor: deposits (and returns None) unless it is the last consumer."""
+    job, deposit = _dgrad_joined_prepare(join, dy, weight4, k, stride, in_shape, dtype, packed)
+    return _dgrad_joined_finish(join, _dgrad_launch(job), deposit)
 
 
 # ------------------------------------------------------------------- Conv + BN(train) + act
@@ -1038,6 +1119,244 @@ def conv_bn_act_pair(x, conv_a, bn_a, conv_b, bn_b, act=ACT_SILU):
             else:
                 bn.num_batches_tracked.add_(1)
     return out
+
+
+_DT = 25  # tensors per level of _DetectTrain: x, 4 x (weight, gamma, beta, running_mean, running_var), 2 x (weight, bias)
+
+
+class _DetectTrain(torch.autograd.Function):
+    """the train-mode Detect head of ALL levels (reference head.py:66-74 loops over the levels; per level cv2[i] / cv3[i] are
+    Conv -> Conv -> biased 1x1, head.py:44-59), its stages run in lockstep across the levels: every GEMM stage is ONE launch over the
+    problems of all levels (ymi_conv2d_fwd_multi / ymi_conv2d_bwd_data_multi) - the 40 x 40 and 20 x 20 levels fill a fraction of the
+    chip on their own.  Per level the arithmetic is that of _ConvBnActPair (first convolutions), two _ConvBnAct side by side in one
+    buffer (second convolutions, one BatchNorm pass over both) and two _ConvAffineAct.  Outputs per level: box map [N, 64, H, W] and
+    the class map in a buffer padded to whole 16-byte rows."""
+
+    @staticmethod
+    def forward(ctx, meta, *t):
+        nl, eps, momentum, joins, ncpad = meta
+        lv = [t[l * _DT : (l + 1) * _DT] for l in range(nl)]
+        dtype, dev = lv[0][0].dtype, lv[0][0].device
+        lib = L()
+        geo, bufs = [], []
+        need = 0
+        for v in lv:
+            n, cp, h, w = v[0].shape
+            c2, c3 = v[1].shape[0], v[6].shape[0]
+            o, m = c2 + c3, n * h * w
+            rows = lib.ymi_conv2d_stat_blocks(m, o)
+            geo.append((n, cp, h, w, c2, c3, o, m, need, rows))
+            need += 2 * (rows * 2 * o + 2 * o) * 4  # two BatchNorm stages: scale, shift, statistics rows
+            _note_use(v[1], v[6], v[11], v[16], v[21], v[23])
+        ws = workspace(need, dev, "detect").view(torch.float32)
+
+        def region(g, stage):
+            n, cp, h, w, c2, c3, o, m, off, rows = g
+            base = off // 4 + stage * (rows * 2 * o + 2 * o)
+            return ws[base : base + o], ws[base + o : base + 2 * o], ws[base + 2 * o : base + 2 * o + rows * 2 * o]
+
+        def bn_stage(probs_of_level, stage, raws, params):
+            """the multi-problem GEMM of a stage, then per level: statistics -> scale / shift, affine + SiLU."""
+            _conv_fwd_multi([p for ps in probs_of_level for p in ps], dtype)
+            outs, stats = [], []
+            for g, ps, raw, (ga, ba, rma, rva, gb, bb, rmb, rvb) in zip(geo, probs_of_level, raws, params):
+                n, cp, h, w, c2, c3, o, m, off, rows = g
+                blocks = ps[0]["blocks"]
+                if any(p["blocks"] != blocks for p in ps):
+                    raise RuntimeError("_DetectTrain: the convolutions of one BatchNorm group ran with different row tiles")
+                scale, shift, part = region(g, stage)
+                st = torch.empty((2, o), dtype=torch.float32, device=dev)
+                out = empty_nhwc(n, o, h, w, dtype, dev)
+                check(lib.ymi_bn_finalize_pair(ptr(part), blocks, m, o, c2, ptr(ga), ptr(ba), ptr(rma), ptr(rva), ptr(gb), ptr(bb), ptr(rmb), ptr(rvb),
+                                               momentum, eps, ptr(scale), ptr(shift), ptr(st[0]), ptr(st[1]), stream_ptr()), "bn_finalize_pair")
+                check(lib.ymi_scale_shift_act(_byref(as_ymi(raw)), ptr(scale), ptr(shift), ACT_SILU, None, _byref(as_ymi(out)), stream_ptr()), "scale_shift_act")
+                outs.append(out)
+                stats.append(st)
+            return outs, stats
+
+        # stage 1: the two first convolutions of a level as ONE (they read the same input)
+        raw1 = [empty_nhwc(g[0], g[6], g[2], g[3], dtype, dev) for g in geo]
+        probs = [[{"x": v[0], "wp": pack_conv_fwd_pair(v[1], v[6], g[1], dtype), "cout": g[6], "k": v[1].shape[2], "y": r, "part": region(g, 0)[2],
+                   "pstride": g[6], "poff": 0}] for v, g, r in zip(lv, geo, raw1)]
+        h1, st1 = bn_stage(probs, 0, raw1, [(v[2], v[3], v[4], v[5], v[7], v[8], v[9], v[10]) for v in lv])
+        # stage 2: the second convolutions read their half of h1 and write their half of one buffer; one BatchNorm pass over both
+        raw2 = [empty_nhwc(g[0], g[6], g[2], g[3], dtype, dev) for g in geo]
+        probs = []
+        for v, g, hh, r in zip(lv, geo, h1, raw2):
+            c2, c3, o = g[4], g[5], g[6]
+            part = region(g, 1)[2]
+            probs.append([{"x": hh[:, :c2], "wp": pack_conv_fwd(v[11], c2, dtype), "cout": c2, "k": v[11].shape[2], "y": r[:, :c2], "part": part, "pstride": o, "poff": 0},
+                          {"x": hh[:, c2:], "wp": pack_conv_fwd(v[16], c3, dtype), "cout": c3, "k": v[16].shape[2], "y": r[:, c2:], "part": part, "pstride": o, "poff": c2}])
+        h2, st2 = bn_stage(probs, 1, raw2, [(v[12], v[13], v[14], v[15], v[17], v[18], v[19], v[20]) for v in lv])
+        # stage 3: the biased 1x1 outputs
+        outs, probs = [], []
+        for v, g, hh in zip(lv, geo, h2):
+            n, cp, h, w, c2, c3 = g[:6]
+            ob, nc = v[21].shape[0], v[23].shape[0]
+            box = empty_nhwc(n, ob, h, w, dtype, dev)
+            cls = empty_nhwc(n, ncpad, h, w, dtype, dev)  # (padded channels are never read: see _ConvAffineAct)
+            probs += [{"x": hh[:, :c2], "wp": pack_conv_fwd(v[21], c2, dtype), "cout": ob, "k": 1, "bias": v[22], "y": box},
+                      {"x": hh[:, c2:], "wp": pack_conv_fwd(v[23], c3, dtype), "cout": nc, "k": 1, "bias": v[24], "y": cls[:, :nc] if ncpad != nc else cls}]
+            outs += [box, cls]
+        _conv_fwd_multi(probs, dtype)
+        saved = []
+        for v, r1, s1, a1, r2, s2, a2 in zip(lv, raw1, st1, h1, raw2, st2, h2):
+            saved += [v[0], v[1], v[6], v[2], v[3], v[7], v[8], r1, s1, a1, v[11], v[16], v[12], v[13], v[17], v[18], r2, s2, a2, v[21], v[23]]
+        ctx.save_for_backward(*saved)
+        ctx.bias_params = [(v[22] if v[22].requires_grad else None, v[24] if v[24].requires_grad else None) for v in lv]  # (leaf parameters: no cycle)
+        ctx.meta = (nl, joins, ncpad, [g[:7] for g in geo])
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *gout):
+        nl, joins, ncpad, geo = ctx.meta
+        S = 21
+        sv = [ctx.saved_tensors[l * S : (l + 1) * S] for l in range(nl)]
+        dtype, dev = sv[0][0].dtype, sv[0][0].device
+        lib = L()
+        nig = ctx.needs_input_grad
+        grads = [None] * (1 + nl * _DT)
+
+        def need(l, i):
+            return nig[1 + l * _DT + i]
+
+        def put(l, i, g):
+            grads[1 + l * _DT + i] = g
+
+        def bn_bwd(dout, raw, ga, ba, gb, bb, c2, st, o):
+            draw = empty_nhwc(*raw.shape, dtype, dev)
+            dgamma = torch.empty(o, dtype=torch.float32, device=dev)
+            dbeta = torch.empty(o, dtype=torch.float32, device=dev)
+            ws = workspace(2048 * 2 * o * 4 + 256, dev, "bnbwd")
+            check(lib.ymi_bn_act_bwd_pair(_byref(as_ymi(dout)), _byref(as_ymi(raw)), ptr(ga), ptr(ba), ptr(gb), ptr(bb), c2, ptr(st[0]), ptr(st[1]), ACT_SILU,
+                                          _byref(as_ymi(draw)), ptr(dgamma), ptr(dbeta), ptr(ws), ws.numel(), stream_ptr()), "bn_act_bwd_pair")
+            return draw, dgamma, dbeta
+
+        # stage 3: data gradients of the 1x1 outputs into the two halves of dh2, weight / bias gradients per convolution
+        jobs, dh2, dys = [], [], []
+        for l in range(nl):
+            n, cp, h, w, c2, c3, o = geo[l]
+            wa2, wb2 = sv[l][19], sv[l][20]
+            dbox = gout[2 * l]
+            dcls = gout[2 * l + 1]
+            dbox = grad_nhwc(dbox, dtype) if dbox is not None else torch.zeros((n, h, w, wa2.shape[0]), dtype=dtype, device=dev).permute(0, 3, 1, 2)
+            dcls = grad_nhwc(dcls, dtype) if dcls is not None else torch.zeros((n, h, w, ncpad), dtype=dtype, device=dev).permute(0, 3, 1, 2)
+            buf = empty_nhwc(n, o, h, w, dtype, dev)
+            jobs.append(_dgrad_prepare(dbox, None, 1, 1, (n, c2, h, w), dtype, [], buf[:, :c2], (pack_conv_dgrad(wa2, dbox.shape[1], 1, dtype), c2)))
+            jobs.append(_dgrad_prepare(dcls, None, 1, 1, (n, c3, h, w), dtype, [], buf[:, c2:], (pack_conv_dgrad(wb2, dcls.shape[1], 1, dtype), c3)))
+            dh2.append(buf)
+            dys.append((dbox, dcls))
+        _dgrad_multi(jobs, dtype)
+        for l in range(nl):
+            n, cp, h, w, c2, c3, o = geo[l]
+            h2 = sv[l][18]
+            for which, (wt, xin, cin, dy) in enumerate(((sv[l][19], h2[:, :c2], c2, dys[l][0]), (sv[l][20], h2[:, c2:], c3, dys[l][1]))):
+                iw = 21 + 2 * which
+                if need(l, iw) or need(l, iw + 1):
+                    dw, db = _wgrad_maybe_async(xin, dy, wt.shape[0], cin, 1, 1, True, (wt, ctx.bias_params[l][which]))
+                    put(l, iw, dw.view(wt.shape) if need(l, iw) else None)
+                    put(l, iw + 1, db if need(l, iw + 1) else None)
+        # stage 2
+        jobs, dh1, draws = [], [], []
+        for l in range(nl):
+            n, cp, h, w, c2, c3, o = geo[l]
+            wa1, wb1, ga, ba, gb, bb, raw2, st2 = sv[l][10:18]
+            draw, dgamma, dbeta = bn_bwd(dh2[l], raw2, ga, ba, gb, bb, c2, st2, o)
+            put(l, 12, dgamma[:c2]); put(l, 13, dbeta[:c2]); put(l, 17, dgamma[c2:]); put(l, 18, dbeta[c2:])
+            buf = empty_nhwc(n, o, h, w, dtype, dev)
+            k = wa1.shape[2]
+            jobs.append(_dgrad_prepare(draw[:, :c2], None, k, 1, (n, c2, h, w), dtype, [], buf[:, :c2], (pack_conv_dgrad(wa1, c2, 1, dtype), c2)))
+            jobs.append(_dgrad_prepare(draw[:, c2:], None, k, 1, (n, c3, h, w), dtype, [], buf[:, c2:], (pack_conv_dgrad(wb1, c3, 1, dtype), c3)))
+            dh1.append(buf)
+            draws.append(draw)
+        dh2 = None
+        _dgrad_multi(jobs, dtype)
+        for l in range(nl):
+            n, cp, h, w, c2, c3, o = geo[l]
+            h1 = sv[l][9]
+            for iw, wt, lo, hi in ((11, sv[l][10], 0, c2), (16, sv[l][11], c2, o)):
+                if need(l, iw):
+                    dw, _ = _wgrad_maybe_async(h1[:, lo:hi], draws[l][:, lo:hi], hi - lo, hi - lo, wt.shape[2], 1, False, (wt,))
+                    put(l, iw, dw)
+        # stage 1
+        jobs, draws = [], []
+        for l in range(nl):
+            n, cp, h, w, c2, c3, o = geo[l]
+            x, wa, wb, ga, ba, gb, bb, raw1, st1 = sv[l][:9]
+            draw, dgamma, dbeta = bn_bwd(dh1[l], raw1, ga, ba, gb, bb, c2, st1, o)
+            put(l, 2, dgamma[:c2]); put(l, 3, dbeta[:c2]); put(l, 7, dgamma[c2:]); put(l, 8, dbeta[c2:])
+            draws.append(draw)
+            if need(l, 0):
+                jobs.append((l,) + _dgrad_joined_prepare(joins[l], draw, None, wa.shape[2], 1, x.shape, dtype, (pack_conv_dgrad_pair(wa, wb, 1, dtype), wa.shape[1])))
+        dh1 = None
+        if jobs:
+            dxs = _dgrad_multi([j[1] for j in jobs], dtype)
+            for (l, _, deposit), dx in zip(jobs, dxs):
+                put(l, 0, _dgrad_joined_finish(joins[l], dx, deposit))
+        for l in range(nl):
+            n, cp, h, w, c2, c3, o = geo[l]
+            x, wa, wb = sv[l][:3]
+            if need(l, 1) or need(l, 6):
+                dw, _ = _wgrad_maybe_async(x, draws[l], o, wa.shape[1], wa.shape[2], 1, False, (wa, wb), pair_rows=c2)
+                put(l, 1, dw[:c2] if need(l, 1) else None)
+                put(l, 6, dw[c2:] if need(l, 6) else None)
+        return tuple(grads)
+
+
+def detect_train_ok(levels, dtype):
+    """the lockstep form needs: at most 4 levels (8 problems a launch), 3x3 / 3x3 / 1x1 stride-1 branches with SiLU Conv blocks, branch
+    widths in whole 16-byte chunks and of ONE width class (both halves of a stage ride in one launch, which fixes the row tile the
+    shared statistics rows are counted in), BatchNorms with one eps / momentum."""
+    if os.environ.get("YMI_DETECT_MULTI", "1") == "0" or not (1 <= len(levels) <= 4):
+        return False
+    ch = chunk_elems(dtype)
+    eps = mom = None
+    for a0, b0, a1, b1, oa, ob in levels:
+        c2, c3 = a0.conv.out_channels, b0.conv.out_channels
+        if c2 % ch or c3 % ch or _width_class(c2, dtype) != _width_class(c3, dtype) or oa.out_channels % ch:
+            return False
+        for m, k in ((a0, 3), (b0, 3), (a1, 3), (b1, 3)):
+            cv, bn = m.conv, getattr(m, "bn", None)
+            if (bn is None or not isinstance(m.act, torch.nn.SiLU) or cv.kernel_size != (k, k) or cv.stride != (1, 1) or cv.groups != 1 or cv.dilation != (1, 1)
+                    or cv.bias is not None or bn.momentum is None):
+                return False
+            if eps is None:
+                eps, mom = bn.eps, bn.momentum
+            if bn.eps != eps or bn.momentum != mom:
+                return False
+        if a1.conv.in_channels != c2 or b1.conv.in_channels != c3 or a0.conv.in_channels != b0.conv.in_channels:
+            return False
+        for m, cin in ((oa, c2), (ob, c3)):
+            if m.kernel_size != (1, 1) or m.stride != (1, 1) or m.in_channels != cin or m.bias is None:
+                return False
+    return True
+
+
+def detect_train(xs, levels):
+    """xs: the internal input tensor of each level; levels: per level (cv2[i][0], cv3[i][0], cv2[i][1], cv3[i][1], cv2[i][2], cv3[i][2]) ->
+    ([box map], [class map]) exactly as the per-level modules would give them."""
+    dtype = xs[0].dtype
+    t, joins = [], []
+    for x, (a0, b0, a1, b1, oa, ob) in zip(xs, levels):
+        t.append(x)
+        for m in (a0, b0, a1, b1):
+            t += [m.conv.weight, m.bn.weight, m.bn.bias, m.bn.running_mean, m.bn.running_var]
+        t += [oa.weight, oa.bias, ob.weight, ob.bias]
+        joins.append(join_of(x))
+    bn0 = levels[0][0].bn
+    nc = levels[0][5].out_channels
+    ncpad = round_up(nc, chunk_elems(dtype))
+    outs = _DetectTrain.apply((len(levels), float(bn0.eps), float(bn0.momentum), joins, ncpad), *t)
+    for lv in levels:
+        for m in lv[:4]:
+            if m.bn.num_batches_tracked is not None:
+                if _deferred_counters is not None:
+                    _deferred_counters.append(m.bn.num_batches_tracked)
+                else:
+                    m.bn.num_batches_tracked.add_(1)
+    box = list(outs[0::2])
+    cls = [(_ChanSlice.apply(c, nc) if ncpad != nc else c) for c in outs[1::2]]
+    return box, cls
 
 
 _deferred_counters = None

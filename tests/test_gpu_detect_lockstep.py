@@ -1,0 +1,173 @@
+"""GPU: the train-mode Detect head with its stages in lockstep across the levels (ops.detect_train: one multi-problem GEMM launch per
+stage, ymi_conv2d_fwd_multi / ymi_conv2d_bwd_data_multi) against the level-by-level modules (reference head.py:66-74 loops over the
+levels) - outputs, every gradient, running statistics, deferred slab sums; and the two multi-problem entry points against their
+one-problem forms on ragged shapes."""
+import ctypes
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-12))
+
+
+def _detect(seed, nc, ch):
+    from improving_yolov8_cbam_swinblock_amd.nn.modules import Detect
+
+    torch.manual_seed(seed)
+    Detect.legacy = True
+    m = Detect(nc, ch).to(dev()).train()
+    m.stride = torch.tensor([8.0, 16.0, 32.0])
+    m.bias_init()
+    for p in m.parameters():
+        if p.dim() == 1 and p.requires_grad:
+            p.data.uniform_(0.5, 1.5)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.eps, mod.momentum = 1e-3, 0.03
+    return m
+
+
+def _run(m, xs, lockstep, dtype, deferred=False, used=None):
+    from improving_yolov8_cbam_swinblock_amd import ops
+
+    m.zero_grad(set_to_none=True)
+    prev = os.environ.get("YMI_DETECT_MULTI")
+    os.environ["YMI_DETECT_MULTI"] = "1" if lockstep else "0"
+    calls = []
+    orig = ops.detect_train
+    ops.detect_train = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        xs = [x.clone().requires_grad_(True) for x in xs]
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=dtype == torch.bfloat16):
+            box, cls = m.forward_split(xs)
+        loss = sum((b.float() * torch.linspace(-1, 1, b.shape[1], device=b.device).view(1, -1, 1, 1)).sum() for b in box) * 1e-3
+        loss = loss + sum(c.float().square().mean() for c in cls)
+        with ops.deferred_wgrad(deferred):
+            loss.backward()
+    finally:
+        ops.detect_train = orig
+        if prev is None:
+            os.environ.pop("YMI_DETECT_MULTI", None)
+        else:
+            os.environ["YMI_DETECT_MULTI"] = prev
+    torch.cuda.synchronize()
+    assert bool(calls) == bool(lockstep), "the lockstep path did not run" if lockstep else "the level-by-level path did not run"
+    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    bufs = {n: b.detach().clone() for n, b in m.named_buffers() if "running" in n or "tracked" in n}
+    return [b.detach().float() for b in box], [c.detach().float() for c in cls], [x.grad.detach().clone() for x in xs], grads, bufs
+
+
+CASES = {"s_nc80": (80, (128, 256, 512), ((24, 24), (12, 12), (6, 6))), "n_nc1": (1, (64, 128, 256), ((20, 12), (10, 6), (5, 3))),
+         "m_nc3": (3, (192, 384, 576), ((8, 8), (4, 4), (2, 2)))}
+
+
+@pytest.mark.parametrize("case", list(CASES))
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_lockstep_detect_matches_the_level_by_level_modules(dtype, case):
+    nc, ch, sizes = CASES[case]
+    m = _detect(0, nc, ch)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    xs = [torch.randn(3, c, h, w, generator=g).to(dev()) for c, (h, w) in zip(ch, sizes)]
+    ref = _run(m, xs, False, dtype)
+    m.load_state_dict(state)
+    got = _run(m, xs, True, dtype)
+    # the same arithmetic per element; what differs is the summation order of the statistics rows / split-K slabs (another row tile) and,
+    # in bfloat16, the roundings that follow from it
+    tol = 2e-5 if dtype == torch.float32 else 1e-2
+    for a, b in zip(got[0] + got[1], ref[0] + ref[1]):
+        assert a.shape == b.shape and rel(a, b) <= (2e-6 if dtype == torch.float32 else 4e-3), rel(a, b)
+    for a, b in zip(got[2], ref[2]):
+        assert rel(a, b) <= tol, rel(a, b)
+    assert set(got[3]) == set(ref[3]) == {n for n, p in m.named_parameters() if p.requires_grad}
+    bad = [(n, rel(got[3][n], ref[3][n])) for n in ref[3] if not rel(got[3][n], ref[3][n]) <= tol]
+    assert not bad, bad[:6]
+    assert set(got[4]) == set(ref[4])
+    bad = [(n, rel(got[4][n], ref[4][n])) for n in ref[4] if not rel(got[4][n], ref[4][n]) <= 1e-5]
+    assert not bad, bad[:6]
+
+
+def test_lockstep_detect_with_deferred_slab_sums_and_frozen_parameters():
+    nc, ch, sizes = CASES["s_nc80"]
+    m = _detect(2, nc, ch)
+    state = {k: v.clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    xs = [torch.randn(2, c, h, w, generator=g).to(dev()) for c, (h, w) in zip(ch, sizes)]
+    ref = _run(m, xs, True, torch.bfloat16, deferred=False)
+    m.load_state_dict(state)
+    got = _run(m, xs, True, torch.bfloat16, deferred=True)
+    bad = [(n, rel(got[3][n], ref[3][n])) for n in ref[3] if not rel(got[3][n], ref[3][n]) <= 1e-5]
+    assert not bad, bad[:6]
+    m.load_state_dict(state)
+    frozen = ("cv3.1.0.conv.weight", "cv2.0.1.conv.weight", "cv3.2.2.weight", "cv2.1.2.bias")
+    for n, p in m.named_parameters():
+        if n in frozen:
+            p.requires_grad_(False)
+    frz = _run(m, xs, True, torch.bfloat16, deferred=True)
+    assert not (set(frozen) & set(frz[3])) and set(frz[3]) == set(ref[3]) - set(frozen)
+    bad = [(n, rel(frz[3][n], ref[3][n])) for n in frz[3] if not rel(frz[3][n], ref[3][n]) <= 1e-5]
+    assert not bad, bad[:6]
+    for a, b in zip(frz[2], ref[2]):
+        assert rel(a, b) <= 1e-6
+
+
+def test_a_detect_the_lockstep_form_does_not_cover_falls_back():
+    """c2 = 64 and c3 = 32 are different K-step classes in bfloat16 (ops.detect_train_ok): the head runs level by level."""
+    from improving_yolov8_cbam_swinblock_amd import ops
+
+    m = _detect(4, 3, (32, 64, 128))
+    levels = [(a[0], b[0], a[1], b[1], a[2], b[2]) for a, b in zip(m.cv2, m.cv3)]
+    assert not ops.detect_train_ok(levels, torch.bfloat16)
+    g = torch.Generator().manual_seed(5)
+    xs = [torch.randn(2, c, s, s, generator=g).to(dev()) for c, s in ((32, 8), (64, 4), (128, 2))]
+    os.environ.pop("YMI_DETECT_MULTI", None)
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        box, cls = m.forward_split([x.clone().requires_grad_(True) for x in xs])
+    assert [tuple(b.shape) for b in box] == [(2, 64, 8, 8), (2, 64, 4, 4), (2, 64, 2, 2)] and all(c.shape[1] == 3 for c in cls)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_multi_problem_entry_points_equal_the_single_problem_ones(dtype):
+    """ragged problems (different maps, widths, kernel sizes, a bias, outputs that are channel slices) through ymi_conv2d_fwd_multi /
+    ymi_conv2d_bwd_data_multi against ymi_conv2d_fwd / ymi_conv2d_bwd_data_add one by one: bit-equal (same tile form or not, every
+    output element is the same K-ordered sum only when the tile's K order agrees - so compared within rounding in bfloat16)."""
+    from improving_yolov8_cbam_swinblock_amd import ops
+    from improving_yolov8_cbam_swinblock_amd._lib import as_ymi, check, empty_nhwc, lib as L, ptr, stream_ptr
+
+    torch.manual_seed(7)
+    d = dev()
+    shapes = [(2, 64, 13, 9, 64, 3), (1, 128, 7, 7, 128, 3), (3, 64, 5, 4, 24, 1), (2, 192, 3, 3, 64, 1), (1, 64, 1, 1, 8, 3)]
+    probs, singles, dprobs = [], [], []
+    for n, cin, h, w, cout, k in shapes:
+        x = torch.randn(n, h, w, cin, device=d).to(dtype).permute(0, 3, 1, 2)
+        wt = torch.randn(cout, cin, k, k, device=d) * 0.05
+        bias = torch.randn(cout, device=d)
+        host = empty_nhwc(n, cout + 16, h, w, dtype, d)
+        y, y1 = host[:, 8 : 8 + cout], empty_nhwc(n, cout, h, w, dtype, d)
+        wp = ops.pack_conv_fwd(wt, cin, dtype)
+        probs.append({"x": x, "wp": wp, "cout": cout, "k": k, "bias": bias, "y": y})
+        check(L().ymi_conv2d_fwd(ctypes.byref(as_ymi(x)), ptr(wp), cout, k, k, 1, None, ptr(bias), 0, None, ctypes.byref(as_ymi(y1)), None, None, stream_ptr()), "fwd")
+        singles.append(y1)
+        dy = torch.randn(n, h, w, cout, device=d).to(dtype).permute(0, 3, 1, 2)
+        add = torch.randn(n, h, w, cin, device=d).to(dtype).permute(0, 3, 1, 2)
+        dprobs.append((dy, wt, k, (n, cin, h, w), add))
+    ops._conv_fwd_multi(probs, dtype)
+    torch.cuda.synchronize()
+    for p, y1 in zip(probs, singles):
+        assert rel(p["y"], y1) <= (1e-6 if dtype == torch.float32 else 4e-3), (tuple(y1.shape), rel(p["y"], y1))
+    jobs = [ops._dgrad_prepare(dy, wt, k, 1, shp, dtype, [add]) for dy, wt, k, shp, add in dprobs]
+    multi = ops._dgrad_multi(jobs, dtype)
+    single = [ops._dgrad(dy, wt, k, 1, shp, dtype, [add]) for dy, wt, k, shp, add in dprobs]
+    torch.cuda.synchronize()
+    for a, b in zip(multi, single):
+        assert rel(a, b) <= (1e-6 if dtype == torch.float32 else 4e-3), (tuple(b.shape), rel(a, b))
