@@ -22,52 +22,10 @@ struct GammaBeta2 {
     const float* beta;
     int split;
 };
-// stage 2: out0[c] = sum_b part[b][0][c], out1[c] = sum_b part[b][1][c]
-// 32 channels x 32 row slices per block, 4 independent accumulator pairs per thread (loads in flight)
-// coefficients of the BN backward apply pass, from the finished sums (one set per channel):
-//   z = x*a0 + a1 ;  draw = dy*act'(z)*c0 - x*c1 - c2
-struct BnCoefArgs {
-    const float* gamma;
-    const float* beta;
-    const float* mean;
-    const float* inv;
-    float inv_count;
-    float* coef;  // [5][C] or nullptr
-    GammaBeta2 g2;
-};
-
-
-// Optional tail of stage 1 (round 4): the LAST workgroup to finish does stage 2 itself, so the separate final launch (a one-to-sixteen
-// workgroup kernel that costs a full dependent-launch latency, ~70 times a step) disappears.  Two levels, both deterministic (fixed
-// rows in fixed order, whoever runs them): the last workgroup of each of the 8 id classes (blockIdx.x & 7) sums that class's rows
-// into xrows[class]; the last of those 8 sums the 8 rows and writes the results / the apply pass's coefficients.  `tickets`: 9
-// counters that are zero between launches (each is reset by the workgroup that sees its final value).  nullptr: no tail.
-struct ReduceTail {
-    unsigned* tickets;
-    double* xrows;  // [8][2][C]
-    float* out0;
-    float* out1;
-    BnCoefArgs bn;
-};
-__device__ __forceinline__ void bn_coef_write(const BnCoefArgs& bn, int C, int c, float s0, float s1) {
-    const bool second = bn.g2.split > 0 && c >= bn.g2.split;
-    const float* gp = second ? bn.g2.gamma : bn.gamma;
-    const float* bp = second ? bn.g2.beta : bn.beta;
-    const int pc = second ? c - bn.g2.split : c;
-    const float ga = gp ? gp[pc] : 1.0f, be = bp ? bp[pc] : 0.0f;
-    const float p0 = bn.inv[c], p1 = -bn.mean[c] * p0;
-    const float k1 = s0 * bn.inv_count, k2 = s1 * bn.inv_count;
-    bn.coef[0 * C + c] = p0 * ga;
-    bn.coef[1 * C + c] = p1 * ga + be;
-    bn.coef[2 * C + c] = ga * p0;
-    bn.coef[3 * C + c] = ga * p0 * p0 * k2;
-    bn.coef[4 * C + c] = ga * p0 * (k1 + p1 * k2);
-}
 template <typename T, int FN, int ACT>
 __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part, GammaBeta2 g2, ReduceTail tail) {
+                                   const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part, GammaBeta2 g2) {
     extern __shared__ float red[];  // [rows][TG][8]
-    __shared__ int s_last;
     const int rows = 256 / TG;
     const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
     const int c0 = blockIdx.y * 1024;  // channels beyond 1024 go to further grid rows
@@ -179,54 +137,25 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, i
             part[((int64_t)blockIdx.x * 2 + 1) * C + c0 + tx * 4 + r] = s1[r];
         }
     }
-    if (tail.tickets == nullptr) return;  // (kernel argument: uniform)
-    // ---- stage 2 by the last workgroups (host: one grid row, C <= 1024) -----------------------------------------------------------------
-    const int xg = blockIdx.x & 7, nbx = gridDim.x >> 3;
-    __threadfence();  // this workgroup's partial row is visible device-wide before its ticket is
-    __syncthreads();
-    if (threadIdx.x == 0) s_last = atomicAdd(&tail.tickets[xg], 1u) == (unsigned)nbx - 1u;
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int col = threadIdx.x; col < 2 * C; col += 256) {  // rows xg, xg + 8, ... : [2][C] floats each, lanes along the columns
-        const float* src = part + (int64_t)xg * 2 * C + col;
-        const int64_t rs = (int64_t)16 * C;  // 8 rows on
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        int j = 0;
-        for (; j + 3 < nbx; j += 4) {
-            a0 += src[(int64_t)j * rs];
-            a1 += src[(int64_t)(j + 1) * rs];
-            a2 += src[(int64_t)(j + 2) * rs];
-            a3 += src[(int64_t)(j + 3) * rs];
-        }
-        for (; j < nbx; ++j) a0 += src[(int64_t)j * rs];
-        tail.xrows[(int64_t)xg * 2 * C + col] = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
-    }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicExch(&tail.tickets[xg], 0u);  // every workgroup of the class has taken its ticket
-        s_last = atomicAdd(&tail.tickets[8], 1u) == 7u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        double a = 0.0, b2 = 0.0;
-#pragma unroll
-        for (int x = 0; x < 8; ++x) {
-            a += tail.xrows[((int64_t)x * 2 + 0) * C + c];
-            b2 += tail.xrows[((int64_t)x * 2 + 1) * C + c];
-        }
-        if (tail.out0) tail.out0[c] = (float)a;
-        if (tail.out1) tail.out1[c] = (float)b2;
-        if (tail.bn.coef) bn_coef_write(tail.bn, C, c, (float)a, (float)b2);
-    }
-    if (threadIdx.x == 0) atomicExch(&tail.tickets[8], 0u);
 }
 
-// stage 2 as its own launch: out0[c] = sum_b part[b][0][c], out1[c] = sum_b part[b][1][c]
+// stage 2: out0[c] = sum_b part[b][0][c], out1[c] = sum_b part[b][1][c]
+// (Its own launch, ~70 a step at a dependent-launch latency each.  Round 4 measured the alternative - the LAST workgroup of stage 1, found
+// with ticket counters behind __threadfence(), does stage 2 - parity-green and 12.85 -> 19.3 ms/step: a device-scope fence is an L2
+// write-back + invalidate on this 8-XCD part and every one of up to 1024 workgroups pays it (17.6 -> 148 us per reduce launch);
+// profiles/r04_bn_tail_ticket_ab.txt, code in git.)
 // 32 channels x 32 row slices per block, 4 independent accumulator pairs per thread (loads in flight)
+// coefficients of the BN backward apply pass, from the finished sums (one set per channel):
+//   z = x*a0 + a1 ;  draw = dy*act'(z)*c0 - x*c1 - c2
+struct BnCoefArgs {
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* inv;
+    float inv_count;
+    float* coef;  // [5][C] or nullptr
+    GammaBeta2 g2;
+};
 
 __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1,
                                                                  BnCoefArgs bn) {
@@ -291,29 +220,6 @@ __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __
     }
 }
 
-// ticket counters of the in-kernel final pass: 1024 slots of 16, zero when the code object loads and again after every launch that used
-// one.  A launch takes the next slot; two launches share a slot only 1024 reduce launches apart (a training step has < 200), so kernels
-// that can be in flight together - the step's side-stream weight gradients beside its main stream - never do.
-__device__ unsigned ymi_ticket_storage[1024 * 16];
-static unsigned* next_ticket_slot() {
-    static thread_local int cached_dev = -1;
-    static thread_local unsigned* base = nullptr;
-    static unsigned counter = 0;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    if (dev != cached_dev) {
-        void* p = nullptr;
-        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ymi_ticket_storage)) != hipSuccess) return nullptr;
-        base = (unsigned*)p;
-        cached_dev = dev;
-    }
-    return base + (size_t)(__atomic_fetch_add(&counter, 1u, __ATOMIC_RELAXED) % 1024u) * 16;
-}
-static bool bn_tail_on() {
-    static const bool on = getenv("YMI_BN_TAIL") && atoi(getenv("YMI_BN_TAIL")) == 1;  // measured 12.85 -> 19.3 ms/step (profiles/r04_bn_tail_ticket_ab.txt): off
-    return on;
-}
-
 static int pow2_ge(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -338,17 +244,16 @@ static int reduce_blocks(int64_t P, int C) {
 template <int FN>
 static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const float* gamma, const float* beta, const float* mean,
                               const float* inv, int act, float* part, int* blocks_out, hipStream_t stream, const char* what,
-                              GammaBeta2 g2 = GammaBeta2{nullptr, nullptr, 0}, ReduceTail tail = ReduceTail{}) {
+                              GammaBeta2 g2 = GammaBeta2{nullptr, nullptr, 0}) {
     const int64_t P = ymi_pixels(a);
     const int C = (int)a->c;
     YMI_CHECK_ARG(C % 4 == 0 && a->ld % 4 == 0 && (!b || (b->ld % 4 == 0)), "%s: channels must be a multiple of 4", what);
     const int TG = pow2_ge(C / 4) > 256 ? 256 : pow2_ge(C / 4);
     const int crows = (C + 1023) / 1024;
     const int blocks = reduce_blocks(P, C);
-    YMI_CHECK_ARG(!tail.tickets || crows == 1, "%s: the in-kernel final pass covers at most 1024 channels", what);
     const size_t lds = (size_t)256 * 8 * sizeof(float);
     RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
-#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, ymi_xcd_span_arg(P), C, TG, gamma, beta, mean, inv, part, g2, tail)
+#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, ymi_xcd_span_arg(P), C, TG, gamma, beta, mean, inv, part, g2)
 #define YMI_CR_T(T)                                                      \
     do {                                                                 \
         if (FN != 1 || act == YMI_ACT_NONE) YMI_CR(T, YMI_ACT_NONE);     \
@@ -585,27 +490,16 @@ static int bn_act_bwd_impl(const ymi_tensor* dout, const ymi_tensor* raw, const 
     const int64_t P = ymi_pixels(dout);
     const int C = (int)dout->c;
     const int rblocks = reduce_blocks(P, C);
-    const size_t need = ((size_t)rblocks * 2 * C + 6 * (size_t)C) * sizeof(float) + 16 * (size_t)C * sizeof(double);
+    const size_t need = ((size_t)rblocks * 2 * C + 5 * (size_t)C) * sizeof(float);
     if (workspace_bytes < need) {
         ymi_set_error("bn_act_bwd: workspace %zu < %zu", workspace_bytes, need);
         return YMI_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     int blocks = 0;
-    float* coef = (float*)workspace + (size_t)rblocks * 2 * C;
-    double* xrows = reinterpret_cast<double*>(coef + 6 * (size_t)C);  // (8-byte aligned: the workspace is, and every term is a multiple of 8 bytes)
-    const BnCoefArgs bn{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef, g2};
-    if (bn_tail_on() && C <= 1024) {
-        // dbeta = sum dz, dgamma = sum dz*xhat and the apply pass's coefficients from the reduce kernel's last workgroups
-        unsigned* tickets = next_ticket_slot();
-        YMI_CHECK_ARG(tickets, "bn_act_bwd: ticket counters");
-        int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)", g2,
-                                       ReduceTail{tickets, xrows, dbeta, dgamma, bn});
-        if (rc) return rc;
-        return launch_bn_apply(dout, raw, draw, act, coef, s);
-    }
     int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)", g2);
     if (rc) return rc;
+    float* coef = (float*)workspace + (size_t)blocks * 2 * C;
     // dbeta = sum dz, dgamma = sum dz*xhat, and the apply pass's coefficients
     hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)workspace, blocks, C, dbeta, dgamma,
                        BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef, g2});

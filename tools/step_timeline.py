@@ -64,16 +64,20 @@ def main():
             od = (ot[k][1] - ot[k][0]) / 1e3
         t = tot[sn]
         t[0] += d
-        t[1] += od or 0.0
         t[2] += 1
         lines.append((k, d, gap, grid // max(wg, 1), wg, sn, od))
     show = sorted(lines, key=lambda l: -l[1])[:top] if top else lines
     for k, d, gap, nb, wg, sn, od in show:
         extra = f" | {od:8.1f} {od - d:+7.1f}" if od is not None else ""
         print(f"{k:4d} {d:8.1f} {gap:6.1f} {nb:7d}x{wg:<4d} {sn}{extra}")
-    print("# per kernel name: us, (other us), launches")
-    for sn, (a, b, n) in sorted(tot.items(), key=lambda kv: -kv[1][0]):
-        print(f"{a:9.1f} {b:9.1f} {n:4d}  {sn}")
+    on = defaultdict(int)
+    if ot is not None:  # the other trace summed BY NAME (the two traces may differ in dispatch count)
+        for s, e, name, grid, wg in ot:
+            tot[short(name)][1] += (e - s) / 1e3
+            on[short(name)] += 1
+    print("# per kernel name: us, (other us), launches" + (", (other launches)" if ot is not None else ""))
+    for sn, (a, b, n) in sorted(tot.items(), key=lambda kv: -max(kv[1][0], kv[1][1])):
+        print(f"{a:9.1f} {b:9.1f} {n:4d}" + (f" {on[sn]:4d}" if ot is not None else "") + f"  {sn}")
 
 
 if __name__ == "__main__":
