@@ -4,7 +4,7 @@ Usage (on the GPU box, two separate passes as MI355X_MICROARCH.md prescribes: FE
 one pass):
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- python3 bench.py ...
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_write -- python3 bench.py ...
-    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write profiles/r01_pmc_traffic.json ["yolov8s.yaml bs32 640"]
 
 Units and gfx950 corrections: both counters are in KiB; FETCH_SIZE tallies the 128-byte requests of wide (16 B/lane)
 streaming reads at 64 B, so read bytes = 2 * FETCH_SIZE * 1024 for these kernels (all their global reads are 16-byte
@@ -52,11 +52,14 @@ def kernel_rev():
 
 def main():
     fetch_dir, write_dir, out = sys.argv[1:4]
+    workload = sys.argv[4] if len(sys.argv) > 4 else None  # "<model yaml> bs<batch> <imgsz>" as bench.py names it (absent: the default configuration)
     fetch = collect(fetch_dir, "FETCH_SIZE")
     write = collect(write_dir, "WRITE_SIZE")
     res = {"kernel_rev": kernel_rev(),
            "recipe": "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024, averaged per launch over every launch of the family in the profiled run",
            "families": {}}
+    if workload:
+        res["workload"] = workload
     for fam in FAMILIES:
         fk, fn = fetch[fam]
         wk, wn = write[fam]
