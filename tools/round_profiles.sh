@@ -44,7 +44,7 @@ if [ "$2" != "cfg5only" ]; then
 fi
 if [ "$2" = "cfg5" ] || [ "$2" = "cfg5only" ]; then
   C5="--model yolov8m-cbam-swin384.yaml --batch 16 --imgsz 1280 --no-cpu-baseline"
-  stats cfg5 13 $C5 --no-forward --sustained 0 --steps 10 --warmup 3
+  stats cfg5 21 $C5 --no-forward --sustained 0 --steps 10 --warmup 3
   traffic cfg5_pmc_traffic.json "yolov8m-cbam-swin384.yaml bs16 1280" $C5 --no-forward --sustained 0 --steps 3 --warmup 1
   python3 $root/bench.py $C5 --steps 10 --warmup 3 --sustained 20 > $out/bench_cfg5.json 2> $out/bench_cfg5.err
   echo "cfg5 done"
