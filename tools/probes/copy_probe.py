@@ -1,5 +1,5 @@
 """Development probe: which host-side tensor copies / fills does one eager training step issue?  (captured into the HIP graph they
-become blit kernels).  usage: python tools/copy_probe.py"""
+become blit kernels).  usage: python tools/probes/copy_probe.py"""
 import collections, os, sys, traceback
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

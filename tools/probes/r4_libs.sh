@@ -1,5 +1,5 @@
 #!/bin/bash
-# durations of selected kernels in one training step, per library build (YMI_LIB): tools/r4_libs.sh TAG PATTERN lib1 lib2 ...
+# durations of selected kernels in one training step, per library build (YMI_LIB): tools/probes/r4_libs.sh TAG PATTERN lib1 lib2 ...
 set -e
 tag=$1; pat=$2; shift 2
 root=${GRAFT_REPO_ROOT:-/root/repo}

@@ -1,6 +1,6 @@
 #!/bin/bash
 # quick check of a change: GPU tests (optional), the bench line without the CPU baseline, optional kernel tables
-# usage: tools/r4_quick.sh TAG [tests] [prof]
+# usage: tools/probes/r4_quick.sh TAG [tests] [prof]
 set -e
 tag=$1
 root=${GRAFT_REPO_ROOT:-/root/repo}
