@@ -134,8 +134,7 @@ class DgradProblem(ctypes.Structure):  # ymi_dgrad_problem
 
 class WgradPending(ctypes.Structure):
     _fields_ = [("slab", _vp), ("dw", _vp), ("elems", _c_i64), ("splits", _c_i32), ("ng", _c_i32), ("cin", _c_i32), ("cout_real", _c_i32),
-                ("cin_real", _c_i32), ("ntaps", _c_i32), ("lanes", _c_i32), ("first_block", _c_i32), ("blocks", _c_i32), ("slab_bf16", _c_i32),
-                ("bias_slab", _vp), ("dbias", _vp)]
+                ("cin_real", _c_i32), ("ntaps", _c_i32), ("lanes", _c_i32), ("first_block", _c_i32), ("blocks", _c_i32), ("slab_bf16", _c_i32)]
 
 
 class OptEntry(ctypes.Structure):

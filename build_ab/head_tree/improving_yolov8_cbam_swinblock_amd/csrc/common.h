@@ -1,0 +1,222 @@
+// Shared device/host helpers for libyolo_mi355.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/ymi.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+#define YMI_WAVE 64
+
+// ---- error plumbing (host) -------------------------------------------------------------------
+void ymi_set_error(const char* fmt, ...);
+#define YMI_CHECK_ARG(cond, ...)          \
+    do {                                  \
+        if (!(cond)) {                    \
+            ymi_set_error(__VA_ARGS__);   \
+            return YMI_EINVAL;            \
+        }                                 \
+    } while (0)
+#define YMI_CHECK_LAUNCH(what)                                                   \
+    do {                                                                         \
+        hipError_t e_ = hipGetLastError();                                       \
+        if (e_ != hipSuccess) {                                                  \
+            ymi_set_error("%s: launch failed: %s", what, hipGetErrorString(e_)); \
+            return YMI_ELAUNCH;                                                  \
+        }                                                                        \
+    } while (0)
+
+static inline bool ymi_tensor_ok(const ymi_tensor* t) {
+    return t && t->data && t->n > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c && (t->dtype == YMI_F32 || t->dtype == YMI_BF16);
+}
+static inline int64_t ymi_pixels(const ymi_tensor* t) { return t->n * t->h * t->w; }
+static inline size_t ymi_esize(int dtype) { return dtype == YMI_BF16 ? 2 : 4; }
+static inline bool ymi_same_shape(const ymi_tensor* a, const ymi_tensor* b) {
+    return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c;
+}
+// grid sizing of the streaming BatchNorm kernels (tuning knobs YMI_EW_PPT / YMI_EW_CAP): pixels each thread should get so
+// that its per-channel coefficient loads amortise, and the workgroup cap
+int ew_ppt();
+int ew_cap();
+// a 16-byte block of zeros in device memory (source of out-of-bounds im2col taps)
+const void* ymi_zero_page();
+
+// ---- element access helpers (device) ----------------------------------------------------------
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float> {
+    static constexpr int CH = 4;  // elements per 16-byte chunk
+    static constexpr int DT = YMI_F32;
+};
+template <> struct ElemTraits<bf16_t> {
+    static constexpr int CH = 8;
+    static constexpr int DT = YMI_BF16;
+};
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-safe
+
+// load / store a group of G consecutive elements as floats (vector access when aligned by construction)
+template <typename T, int G> struct Pack;
+template <> struct Pack<float, 4> {
+    static __device__ __forceinline__ void load(const float* p, float (&v)[4]) {
+        f32x4 t = *reinterpret_cast<const f32x4*>(p);
+        v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3];
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&v)[4]) {
+        f32x4 t = {v[0], v[1], v[2], v[3]};
+        *reinterpret_cast<f32x4*>(p) = t;
+    }
+};
+template <> struct Pack<bf16_t, 4> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[4]) {
+        bf16x4 t = *reinterpret_cast<const bf16x4*>(p);
+        v[0] = (float)t[0]; v[1] = (float)t[1]; v[2] = (float)t[2]; v[3] = (float)t[3];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[4]) {
+        bf16x4 t = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+        *reinterpret_cast<bf16x4*>(p) = t;
+    }
+};
+template <> struct Pack<bf16_t, 8> {
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&v)[8]) {
+        bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = (float)t[i];
+    }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&v)[8]) {
+        bf16x8 t;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[i] = (bf16_t)v[i];
+        *reinterpret_cast<bf16x8*>(p) = t;
+    }
+};
+
+// e^x as one v_exp_f32 (2^(x*log2 e)): ~1 ulp, results below 2^-126 flush to zero; no range-reduction code
+// four consecutive elements as they lie in memory (8 bytes of bfloat16, 16 bytes of float32) and their conversion
+template <typename T> struct Raw4;
+template <> struct Raw4<bf16_t> {
+    typedef bf16x4 type;
+    static __device__ __forceinline__ void to_f32(const bf16x4& r, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = (float)r[i];
+    }
+};
+template <> struct Raw4<float> {
+    typedef f32x4 type;
+    static __device__ __forceinline__ void to_f32(const f32x4& r, float (&v)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = r[i];
+    }
+};
+
+// Workgroups are dealt round-robin to the 8 XCDs (flat id & 7), each with its own L2.  Work units that read neighbouring bytes
+// (the 16-byte channel chunks of one 128-byte line, the heads of one token row) should therefore NOT sit on consecutive flat
+// ids: every XCD would fetch the whole line.  xcd_unit() turns the flat workgroup id into a work-unit index such that
+// consecutive UNITS run on one XCD, back to back (a permutation of [0, total) when total % 8 == 0, the identity otherwise).
+// ---- XCD ownership of the pixel axis (round 4) -----------------------------------------------------------------------------------
+// A consumer finds its producer's bytes in its own XCD's L2 - 3.7-6x faster for a latency-shaped reader such as a GEMM's operand
+// ring than from another XCD's L2 / the Infinity Cache (profiles/r04_xcd_affinity_probe.txt) - when both kernels give an XCD the
+// same part of the tensor.  ONE rule for every kernel that walks pixels (or tokens): the XCD a workgroup runs on (flat id & 7:
+// workgroups are dealt round-robin, measured stable from launch to launch) owns the pixels [x * span, (x + 1) * span) of the
+// batch-major pixel order, span = ymi_xcd_span(P).  The rule is a FRACTION of the pixel order, so it lines up across resolutions
+// (a stride-2 consumer's eighth of the output reads the same eighth of its input), and at batch sizes that are multiples of 8 it is
+// whole images.  Placement is a speed matter only: nothing depends on it for correctness.
+__host__ __device__ __forceinline__ int64_t ymi_xcd_span(int64_t P) { return (((P + 63) >> 6) + 7) >> 3 << 6; }
+// the pixel range [lo, hi) of this workgroup's XCD, the workgroup's index among that XCD's workgroups and their number
+// (the launch grid must be a multiple of 8 workgroups)
+struct XcdRange {
+    int64_t lo, hi;
+    int bi, nbx;
+};
+int64_t ymi_xcd_span_arg(int64_t P);  // host: ymi_xcd_span(P), with the diagnostic shift of YMI_XCD_SHIFT in bits 56..58
+__device__ __forceinline__ XcdRange xcd_range(int64_t P, int64_t span_arg) {
+    const int id = blockIdx.x, x = ((id & 7) + (int)(span_arg >> 56)) & 7;
+    const int64_t span = span_arg & ((1ll << 56) - 1);
+    XcdRange r;
+    r.lo = x * span;
+    r.hi = r.lo + span < P ? r.lo + span : P;
+    if (r.lo > P) r.lo = P;
+    r.bi = id >> 3;
+    r.nbx = gridDim.x >> 3;
+    return r;
+}
+
+__device__ __forceinline__ int xcd_unit(int flat, int total) { return (total & 7) ? flat : (flat & 7) * (total >> 3) + (flat >> 3); }
+__device__ __forceinline__ int flat_block_id() { return blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z); }
+
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
+// 1 / (1 + e^-x) with v_exp_f32 + v_rcp_f32 (each ~1 ulp) instead of the IEEE division sequence
+__device__ __forceinline__ float sigmoidf_(float x) { return __builtin_amdgcn_rcpf(1.0f + fast_exp(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad_f(float x) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+// erf(z) by Abramowitz & Stegun 7.1.26: 1 - (a1 t + .. + a5 t^5) e^(-z^2), t = 1 / (1 + p |z|); absolute error <= 1.5e-7 - float32 noise
+// next to the 1 the GELU adds it to - in 6 multiply-adds, v_rcp_f32 and v_exp_f32.  libm's erff is ~45 instructions with two branches
+// that a wave executes both of; in the Swin MLP's GEMM epilogues (32768 activations per 256 x 128 tile) that was as long as the K loop.
+// e2 (optional): receives e^(-z^2), which GELU's derivative needs as well.
+__device__ __forceinline__ float erf_as(float z, float* e2 = nullptr) {
+    const float az = fabsf(z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * az);
+    const float e = fast_exp(-az * az);
+    float p = 1.061405429f;
+    p = p * t - 1.453152027f;
+    p = p * t + 1.421413741f;
+    p = p * t - 0.284496736f;
+    p = p * t + 0.254829592f;
+    if (e2) *e2 = e;
+    return copysignf(1.0f - p * t * e, z);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    const float c = 0.39894228040143267794f;  // 1/sqrt(2 pi)
+    float e;                                   // e^(-x^2 / 2)
+    const float er = erf_as(x * 0.70710678118654752440f, &e);
+    return 0.5f * (1.0f + er) + x * c * e;
+}
+template <int ACT> __device__ __forceinline__ float apply_act(float x) {
+    if (ACT == YMI_ACT_SILU) return silu_f(x);
+    if (ACT == YMI_ACT_GELU) return gelu_f(x);
+    return x;
+}
+__device__ __forceinline__ float apply_act_rt(float x, int act) {
+    return act == YMI_ACT_SILU ? silu_f(x) : act == YMI_ACT_GELU ? gelu_f(x) : x;
+}
+template <int ACT> __device__ __forceinline__ float act_grad(float x) {
+    if (ACT == YMI_ACT_SILU) return silu_grad_f(x);
+    if (ACT == YMI_ACT_GELU) return gelu_grad_f(x);
+    return 1.0f;
+}
+__device__ __forceinline__ float act_grad_rt(float x, int act) {
+    return act == YMI_ACT_SILU ? silu_grad_f(x) : act == YMI_ACT_GELU ? gelu_grad_f(x) : 1.0f;
+}
+
+// retire all but the N youngest vector-memory operations of this wave, then meet the workgroup: bytes written
+// to LDS by LDS-DMA (global_load_lds) are readable by other waves only after BOTH (counted wait, then barrier).
+template <int N> __device__ __forceinline__ void wait_vmcnt_barrier() {
+    asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// wave-level reductions (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}

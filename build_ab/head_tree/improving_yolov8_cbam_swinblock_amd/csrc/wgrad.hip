@@ -46,7 +46,6 @@ struct WgradArgs {
     const void* dy;
     void* slab;
     int slab_bf16;
-    float* bias_slab;  // optional [splits][CoutP]: column sums of dY per split (the bias gradient's partials), formed by the tiles of column block 0
     const void* zero;
     int64_t ldx, ldy;
     int Mpix, H, W, Ho, Wo;
@@ -102,7 +101,7 @@ template <> struct WFrag<bf16_t> {
         return __builtin_bit_cast(bf16x8, v);
     }
     template <int BM, int TR, int TC, int BNW = WG_BN>
-    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC], bool bias, f32x4 (&accb)[TR]) {
+    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 32; ++ks) {  // pixel rows 32*ks .. 32*ks+31 (the swizzles use row bits 0..3 only)
             const char* Yk = Ys + ks * 32 * BM * 2;
@@ -118,19 +117,12 @@ template <> struct WFrag<bf16_t> {
             for (int a = 0; a < TR; ++a)
 #pragma unroll
                 for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);  // operands swapped: see the epilogue
-            if (bias) {  // (wave-uniform) column sums of dY: a row of ones against the dY fragments already in registers - TR more MFMAs
-                typedef __attribute__((ext_vector_type(8))) short s16x8;
-                const s16x8 one8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // 1.0 in bfloat16
-                const bf16x8 ones = __builtin_bit_cast(bf16x8, one8);
-#pragma unroll
-                for (int a = 0; a < TR; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], accb[a], 0, 0, 0);
-            }
         }
     }
 };
 template <> struct WFrag<float> {
     template <int BM, int TR, int TC, int BNW = WG_BN>
-    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC], bool bias, f32x4 (&accb)[TR]) {
+    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC]) {
         static_assert(BNW == WG_BN, "f32 parity mode uses the 128-column tile");
         const int kq = lane >> 4, i = lane & 15;
 #pragma unroll
@@ -144,10 +136,6 @@ template <> struct WFrag<float> {
             for (int a = 0; a < TR; ++a)
 #pragma unroll
                 for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[b], af[a], acc[a][b], 0, 0, 0);
-            if (bias) {
-#pragma unroll
-                for (int a = 0; a < TR; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[a], accb[a], 0, 0, 0);
-            }
         }
     }
 };
@@ -295,11 +283,6 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
 #pragma unroll
         for (int c = 0; c < TC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // bias gradient (column sums of dY): formed by the waves of column block 0 that own the first 64 columns - every (row block, split) once
-    const bool do_bias = a.bias_slab != nullptr && bx == 0 && wc == 0;  // (wave-uniform)
-    f32x4 accb[TR];
-#pragma unroll
-    for (int r = 0; r < TR; ++r) accb[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     WG_MARK(0);  // prologue done
     // NS-stage LDS ring, one raw barrier per K step, loads of NS-2 younger steps stay in flight (see igemm.hip)
     const int nk = (m_end - m_begin + WG_BK - 1) / WG_BK;
@@ -323,7 +306,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, m_begin + (kt + NS - 1) * WG_BK);
         WG_STEP_STAMP();  // 2: pieces issued
         const char* Ys = smem + (kt % NS) * STAGE;
-        WFrag<T>::template step<BM, TR, TC, BNW>(Ys, Ys + YBYTES, wr * (BM / WROWS), wc * 64, lane, acc, do_bias, accb);
+        WFrag<T>::template step<BM, TR, TC, BNW>(Ys, Ys + YBYTES, wr * (BM / WROWS), wc * 64, lane, acc);
         WG_STEP_STAMP();  // 3: fragments read, MFMAs issued
     }
 
@@ -339,13 +322,6 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     // CONSECUTIVE (tap, ci) columns of one output channel: one 16-byte store instead of four 4-byte stores to four rows
     // (stores are issue-bound on this chip: 8 / 16 instructions per lane instead of 32 / 64).  NG is a multiple of 4.
     const int l15 = lane & 15, l4 = lane >> 4;
-    if (do_bias && l4 == 0) {  // every row of the ones product holds the same sums: lanes 0-15 write their output channel's
-#pragma unroll
-        for (int r = 0; r < TR; ++r) {
-            const int co = co0 + wr * (BM / WROWS) + r * 16 + l15;
-            if (co < a.CoutP) a.bias_slab[(int64_t)bz * a.CoutP + co] = accb[r][0];
-        }
-    }
 #pragma unroll
     for (int r = 0; r < TR; ++r) {
         const int co = co0 + wr * (BM / WROWS) + r * 16 + l15;
@@ -420,27 +396,7 @@ __global__ void wgrad_reduce_kernel(const void* __restrict__ slab, int splits, i
 // tensor by binary search over the table's first_block column, then sums `lanes` interleaved split chains per output
 // element in a fixed order (deterministic) and scatters into OIHW.  By the end of the backward pass the slabs have left the
 // caches: this kernel streams them from HBM, 4 elements per lane and load, four split chains in flight per lane.
-// dbias[co] = sum over the splits of the bias partials [split][coutp], four chains in flight, fixed order
-__device__ __forceinline__ void bias_slab_sum(const float* __restrict__ bs, int splits, int coutp, float* __restrict__ db, int tid, int nthr) {
-    for (int co = tid; co < coutp; co += nthr) {
-        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-        int k = 0;
-        for (; k + 3 < splits; k += 4) {
-            s0 += bs[(int64_t)k * coutp + co];
-            s1 += bs[(int64_t)(k + 1) * coutp + co];
-            s2 += bs[(int64_t)(k + 2) * coutp + co];
-            s3 += bs[(int64_t)(k + 3) * coutp + co];
-        }
-        for (; k < splits; ++k) s0 += bs[(int64_t)k * coutp + co];
-        db[co] = (s0 + s1) + (s2 + s3);
-    }
-}
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bs, int splits, int coutp, float* __restrict__ db) {
-    bias_slab_sum(bs, splits, coutp, db, (int)(blockIdx.x * blockDim.x + threadIdx.x), (int)(gridDim.x * blockDim.x));
-}
 template <bool BF> __device__ __forceinline__ void reduce_batch_body(const ymi_wgrad_pending& e, f32x4* red) {
-    // the record's first workgroup also sums the bias partials (a few KB)
-    if (e.bias_slab && (int)blockIdx.x == e.first_block) bias_slab_sum(e.bias_slab, e.splits, (int)(e.elems / e.ng), e.dbias, (int)threadIdx.x, 256);
     // a lane owns EPT consecutive elements: 8 (one 16-byte load per split) of a bfloat16 slab, 4 of a float32 slab
     constexpr int EPT = BF ? 8 : 4, Q = EPT / 4;
     const int SL = e.lanes, OUTS = 256 / SL;              // OUTS groups of EPT consecutive elements per workgroup
@@ -570,8 +526,7 @@ extern "C" int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_ten
 
 // the records travel to the device table in kernel ARGUMENTS (by value): no host staging buffer, so the launches are
 // graph-capturable (a captured host-to-device copy would re-read its host buffer at replay time)
-constexpr int WG_TABLE_CHUNK = 48;  // 48 x 80 B = 3.75 KB of kernel arguments
-static_assert(sizeof(ymi_wgrad_pending) == 80, "ymi_wgrad_pending layout (mirrored in _lib.py)");
+constexpr int WG_TABLE_CHUNK = 56;  // 56 x 64 B = 3.5 KB of kernel arguments
 struct WgradTableChunk {
     ymi_wgrad_pending e[WG_TABLE_CHUNK];
 };
@@ -630,9 +585,6 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     }
     WgradArgs a{};
     a.x = x->data; a.dy = dy->data; a.slab = workspace; a.slab_bf16 = slab_bf16 ? 1 : 0; a.zero = ymi_zero_page();
-    // bias gradient: per-split column sums of dY come out of the GEMM itself (a ones row against the dY fragments), behind the slabs
-    a.bias_slab = dbias ? reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.slab_bytes) : nullptr;
-    YMI_CHECK_ARG(!dbias || (size_t)p.splits * dy->c <= (size_t)(2048 * 2 + 1) * dy->c, "conv2d_bwd_weight: too many splits for the bias partials");
     a.ldx = x->ld; a.ldy = dy->ld;
     a.Mpix = (int)mpix; a.H = (int)x->h; a.W = (int)x->w; a.Ho = (int)dy->h; a.Wo = (int)dy->w;
     a.stride = (int)stride; a.pad = (int)pad; a.KW = (int)kw;
@@ -667,7 +619,7 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
         const int lanes = p.splits > 128 ? 32 : p.splits > 32 ? 16 : p.splits > 8 ? 8 : 4;
         const int ept = a.slab_bf16 ? 8 : 4;  // elements per lane of the batched sum (one 16-byte load per split)
         *pending = ymi_wgrad_pending{a.slab, dw_oihw, elems, p.splits, a.NG, a.Cin, (int32_t)cout_real, (int32_t)cin_real, (int32_t)(kh * kw), lanes, 0,
-                                     (int32_t)((elems / ept + 256 / lanes - 1) / (256 / lanes)), a.slab_bf16, a.bias_slab, dbias};
+                                     (int32_t)((elems / ept + 256 / lanes - 1) / (256 / lanes)), a.slab_bf16};
     } else {
         const int64_t total = cout_real * kh * kw * cin_real;
         int64_t gb = (total + 255) / 256;
@@ -678,10 +630,11 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
                                 (int)cout_real, (int)cin_real, (int)(kh * kw), dw_oihw);
     }
     YMI_CHECK_LAUNCH("wgrad_reduce");
-    if (dbias && !pending) {
-        // bias gradient: the sum of the per-split column sums, written straight into the caller's buffer of dy->c floats (the real channels come first)
-        hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((unsigned)((dy->c + 255) / 256)), dim3(256), 0, s, (const float*)a.bias_slab, p.splits, (int)dy->c, dbias);
-        YMI_CHECK_LAUNCH("wgrad_bias_reduce");
+    if (dbias) {
+        // bias gradient: column sums of dy, written straight into the caller's buffer of dy->c floats (the real channels come first)
+        float* part = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + p.slab_bytes);
+        int rc = ymi_colsum(dy, dbias, part, (size_t)2048 * 2 * dy->c * sizeof(float), stream);
+        if (rc) return rc;
     }
     return YMI_OK;
 }

@@ -329,8 +329,7 @@ def _wgrad(x, dy, cout, cin, k, stride, want_bias, params=(), pair_rows=None):
     pair_rows: params are TWO weights whose gradients are the row ranges [0, pair_rows) and [pair_rows, cout) of dw (_ConvBnActPair)."""
     if _deferred["on"] and _in_backward() and _adoptable(params) and not _deferred_twice(params):
         owner = (params[0], params[1], int(pair_rows)) if pair_rows else (params[0] if params else None)
-        bias_owner = params[1] if (want_bias and not pair_rows and len(params) > 1) else None
-        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner, _new_dw(cout, cin, k, x.device, params, pair_rows), bias_owner)
+        return _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner, _new_dw(cout, cin, k, x.device, params, pair_rows))
     dev = x.device
     dw = _new_dw(cout, cin, k, dev, params, pair_rows)
     ty, tx = as_ymi(dy), as_ymi(x)
@@ -463,7 +462,7 @@ def _wgrad_maybe_async(x, dy, cout, cin, k, stride, want_bias, params=(), pair_r
 # So the deferral is OPT-IN: engine.trainer.TrainStep, which zeroes gradients with set_to_none=True after every step and
 # knows its DDP schedule, enables it around its backward.  Everywhere else (plain autograd use of the modules, gradient
 # accumulation, hooks) each weight gradient is complete when its Function returns.
-_deferred = {"on": False, "records": [], "keep": [], "owners": [], "bias": [], "task": None, "table": None}
+_deferred = {"on": False, "records": [], "keep": [], "owners": [], "task": None, "table": None}
 
 
 class deferred_wgrad:
@@ -489,8 +488,8 @@ def set_wgrad_deferred(flag):
 
 
 def _flush_wgrads():
-    recs, keep, owners, biases = _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["bias"]
-    _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["bias"], _deferred["task"] = [], [], [], [], None
+    recs, keep, owners = _deferred["records"], _deferred["keep"], _deferred["owners"]
+    _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["task"] = [], [], [], None
     if not recs:
         return
     # Every node of the pass has run: a parameter's AccumulateGrad has either ADOPTED the returned tensor (p.grad is that
@@ -518,36 +517,25 @@ def _flush_wgrads():
     if tab is None or tab.device != dev or tab.numel() < n * ctypes.sizeof(_lib.WgradPending):
         tab = _deferred["table"] = torch.empty(max(n, 128) * ctypes.sizeof(_lib.WgradPending), dtype=torch.uint8, device=dev)
     arr = (_lib.WgradPending * n)(*recs)
-    def late_bias():
-        # bias gradients are summed by the batched launch too (into the buffer their Function returned a view of).  Usually AccumulateGrad
-        # adopted that view; where it stored a clone instead, the clone gets the finished sum here
-        for b in biases:
-            if b is not None and b[0] is not None:
-                g = b[0].grad
-                if g is not None and g.data_ptr() != b[1].data_ptr():
-                    g.copy_(b[1][: b[2]])
-
     if _async["on"]:  # the GEMMs ran on the side stream: the sum follows them there (joined by async_wgrad's exit)
         # (slabs produced on the CURRENT stream - the first layer's fused backward - must be complete too)
         _side_stream(dev).wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(_side_stream(dev)):
             check(L().ymi_wgrad_reduce_batch(arr, n, ptr(tab), stream_ptr()), "wgrad_reduce_batch")
-            late_bias()
         _async["pending"] = True
     else:
         check(L().ymi_wgrad_reduce_batch(arr, n, ptr(tab), stream_ptr()), "wgrad_reduce_batch")
-        late_bias()
     del keep
 
 
-def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None, dw=None, bias_owner=None):
+def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None, dw=None):
     """as _wgrad, with the slab sum left to the end of the backward pass.  Slabs and operands stay alive in _deferred['keep']
     until the flush has been enqueued; the gradient tensor itself is owned by autograd (see _flush_wgrads).  owner: the weight."""
     task = torch._C._current_graph_task_id()
     if _deferred["task"] != task:
         # first deferred gradient of this pass.  Records of an earlier pass whose end-of-pass callback never ran (the engine
         # drops callbacks when a backward raises) are stale: their gradient tensors are gone - discard them.
-        _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["bias"] = [], [], [], []
+        _deferred["records"], _deferred["keep"], _deferred["owners"] = [], [], []
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
         _deferred["task"] = task
     dev = x.device
@@ -561,12 +549,8 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None, dw=None,
     check(L().ymi_conv2d_bwd_weight_deferred(_byref(tx), _byref(ty), cout, cin, k, k, stride, ptr(dw), ptr(db), ptr(ws), ws.numel(), _byref(rec), stream_ptr()),
           "conv2d_bwd_weight")
     _deferred["records"].append(rec)
-    # (db, the BASE of the returned bias-gradient view, stays referenced until the flush: the batched sum also writes the bias gradient
-    # - its per-split partials come out of the GEMM - so that memory must not return to the allocator first; holding the base does not
-    # keep AccumulateGrad from adopting the view)
-    _deferred["keep"].append((ws, x, dy, db))
+    _deferred["keep"].append((ws, x, dy))
     _deferred["owners"].append(owner)
-    _deferred["bias"].append((bias_owner, db, cout) if want_bias else None)
     return dw, (db[:cout] if want_bias else None)
 
 
@@ -949,13 +933,12 @@ class _FirstConvBnAct(torch.autograd.Function):
         if defer:
             task = torch._C._current_graph_task_id()
             if _deferred["task"] != task:
-                _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["bias"] = [], [], [], []
+                _deferred["records"], _deferred["keep"], _deferred["owners"] = [], [], []
                 torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
                 _deferred["task"] = task
             _deferred["records"].append(rec)
             _deferred["keep"].append((ws, x4, dout))
             _deferred["owners"].append(weight)
-            _deferred["bias"].append(None)
         return None, (dw if ctx.needs_input_grad[1] else None), dgamma, dbeta, None, None, None, None, None
 
 

@@ -225,8 +225,6 @@ typedef struct ymi_wgrad_pending {
     int32_t first_block; /* set by ymi_wgrad_reduce_batch */
     int32_t blocks;      /* workgroups this record needs: ceil(elems / e / (256 / lanes)), e = 8 elements per lane for bfloat16 slabs, 4 for float32 */
     int32_t slab_bf16;   /* 1: the slabs hold bfloat16 (the bf16 path), 0: float32 (parity mode) */
-    const float* bias_slab; /* optional: [splits][padded Cout] float32 column sums of dY per split (the bias gradient's partials, formed by the */
-    float* dbias;           /* weight-gradient GEMM itself); their sum over the splits goes to dbias [padded Cout].  NULL: no bias */
 } ymi_wgrad_pending;
 int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
                                    int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
