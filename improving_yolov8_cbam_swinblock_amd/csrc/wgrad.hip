@@ -101,8 +101,8 @@ template <> struct WFrag<bf16_t> {
         s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         return __builtin_bit_cast(bf16x8, v);
     }
-    template <int BM, int TR, int TC, int BNW = WG_BN>
-    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC], bool bias, f32x4 (&accb)[TR]) {
+    template <int BM, int TR, int TC, int BNW = WG_BN, bool BIAS = false>
+    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC], bool bias, f32x4 (&accb)[BIAS ? TR : 1]) {
 #pragma unroll
         for (int ks = 0; ks < WG_BK / 32; ++ks) {  // pixel rows 32*ks .. 32*ks+31 (the swizzles use row bits 0..3 only)
             const char* Yk = Ys + ks * 32 * BM * 2;
@@ -118,19 +118,19 @@ template <> struct WFrag<bf16_t> {
             for (int a = 0; a < TR; ++a)
 #pragma unroll
                 for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);  // operands swapped: see the epilogue
-            if (bias) {  // (wave-uniform) column sums of dY: a row of ones against the dY fragments already in registers - TR more MFMAs
+            if (BIAS && bias) {  // (wave-uniform) column sums of dY: a row of ones against the dY fragments already in registers - TR more MFMAs
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 one8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // 1.0 in bfloat16
                 const bf16x8 ones = __builtin_bit_cast(bf16x8, one8);
 #pragma unroll
-                for (int a = 0; a < TR; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], accb[a], 0, 0, 0);
+                for (int a = 0; a < (BIAS ? TR : 1); ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], accb[a], 0, 0, 0);
             }
         }
     }
 };
 template <> struct WFrag<float> {
-    template <int BM, int TR, int TC, int BNW = WG_BN>
-    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC], bool bias, f32x4 (&accb)[TR]) {
+    template <int BM, int TR, int TC, int BNW = WG_BN, bool BIAS = false>
+    static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC], bool bias, f32x4 (&accb)[BIAS ? TR : 1]) {
         static_assert(BNW == WG_BN, "f32 parity mode uses the 128-column tile");
         const int kq = lane >> 4, i = lane & 15;
 #pragma unroll
@@ -144,9 +144,9 @@ template <> struct WFrag<float> {
             for (int a = 0; a < TR; ++a)
 #pragma unroll
                 for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(bfr[b], af[a], acc[a][b], 0, 0, 0);
-            if (bias) {
+            if (BIAS && bias) {
 #pragma unroll
-                for (int a = 0; a < TR; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[a], accb[a], 0, 0, 0);
+                for (int a = 0; a < (BIAS ? TR : 1); ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(1.0f, af[a], accb[a], 0, 0, 0);
             }
         }
     }
@@ -157,7 +157,9 @@ template <> struct WFrag<float> {
 // layers with <= 32 output channels (the 320x320 / 160x160 maps: millions of pixels against a 32 x 72..288 weight matrix; the
 // 64-row tile spent half its MFMAs on padding rows)
 // (a 128x256 tile - 4 or 8 waves - measured 1.17-1.66x slower, profiles/r02_conv_bench_wgrad256.txt; removed in round 3)
-template <typename T, int NS, int BM>
+// BIAS: the instantiation that also forms the bias gradient's partials (its own code object: the 4 * TR accumulator registers and the branch
+// cost the bias-free launches 3-4 % when they were a run-time option of one kernel)
+template <typename T, int NS, int BM, bool BIAS = false>
 __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
     constexpr int BNW = WG_BN, NT = 256;
     constexpr int CH = ElemTraits<T>::CH;
@@ -296,10 +298,10 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         for (int c = 0; c < TC; ++c) acc[r][c] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // bias gradient (column sums of dY): formed by the waves of column block 0 that own the first 64 columns - every (row block, split) once
-    const bool do_bias = a.bias_slab != nullptr && bx == 0 && wc == 0;  // (wave-uniform)
-    f32x4 accb[TR];
+    const bool do_bias = BIAS && bx == 0 && wc == 0;  // (wave-uniform)
+    f32x4 accb[BIAS ? TR : 1];
 #pragma unroll
-    for (int r = 0; r < TR; ++r) accb[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < (BIAS ? TR : 1); ++r) accb[r] = f32x4{0.f, 0.f, 0.f, 0.f};
     WG_MARK(0);  // prologue done
     // NS-stage LDS ring, one raw barrier per K step, loads of NS-2 younger steps stay in flight (see igemm.hip)
     const int nk = (m_end - m_begin + WG_BK - 1) / WG_BK;
@@ -323,7 +325,8 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         if (kt + NS - 1 < nk) issue((kt + NS - 1) % NS, m_begin + (kt + NS - 1) * WG_BK);
         WG_STEP_STAMP();  // 2: pieces issued
         const char* Ys = smem + (kt % NS) * STAGE;
-        WFrag<T>::template step<BM, TR, TC, BNW>(Ys, Ys + YBYTES, wr * (BM / WROWS), wc * 64, lane, acc, do_bias, accb);
+        if constexpr (BIAS) WFrag<T>::template step<BM, TR, TC, BNW, true>(Ys, Ys + YBYTES, wr * (BM / WROWS), wc * 64, lane, acc, do_bias, accb);
+        else WFrag<T>::template step<BM, TR, TC, BNW, false>(Ys, Ys + YBYTES, wr * (BM / WROWS), wc * 64, lane, acc, false, accb);
         WG_STEP_STAMP();  // 3: fragments read, MFMAs issued
     }
 
@@ -339,9 +342,9 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     // CONSECUTIVE (tap, ci) columns of one output channel: one 16-byte store instead of four 4-byte stores to four rows
     // (stores are issue-bound on this chip: 8 / 16 instructions per lane instead of 32 / 64).  NG is a multiple of 4.
     const int l15 = lane & 15, l4 = lane >> 4;
-    if (do_bias && l4 == 0) {  // every row of the ones product holds the same sums: lanes 0-15 write their output channel's
+    if (BIAS && do_bias && l4 == 0) {  // every row of the ones product holds the same sums: lanes 0-15 write their output channel's
 #pragma unroll
-        for (int r = 0; r < TR; ++r) {
+        for (int r = 0; r < (BIAS ? TR : 1); ++r) {
             const int co = co0 + wr * (BM / WROWS) + r * 16 + l15;
             if (co < a.CoutP) a.bias_slab[(int64_t)bz * a.CoutP + co] = accb[r][0];
         }
@@ -650,16 +653,23 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
         const double bytes = ((double)ymi_pixels(x) * x->c + (double)mpix * dy->c) * es + (double)dy->c * ng * 4.0;
         prof = ymi_prof_start(s, 1, 2.0 * (double)mpix * (double)dy->c * (double)ng, bytes, x->dtype == YMI_BF16 ? 2500.0 : 157.3);
     }
+#define YMI_WG_LAUNCH(T, BMV, LDS)                                                                                   \
+    do {                                                                                                            \
+        if (a.bias_slab) hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, true>), grid, dim3(256), (LDS), s, a);          \
+        else hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, false>), grid, dim3(256), (LDS), s, a);                     \
+    } while (0)
     if (bf16) {
         // two LDS stages (deeper rings measured equal: same bytes in flight per CU)
-        if (bm == 128) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 128>), grid, dim3(256), (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
-        else if (bm == 32) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 32>), grid, dim3(256), (size_t)2 * (WG_BK * (32 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
-        else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 64>), grid, dim3(256), (size_t)2 * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS, s, a);
+        if (bm == 128) YMI_WG_LAUNCH(bf16_t, 128, (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS);
+        else if (bm == 32) YMI_WG_LAUNCH(bf16_t, 32, (size_t)2 * (WG_BK * (32 + WG_BN) * 2) + WG_STAMP_LDS);
+        else YMI_WG_LAUNCH(bf16_t, 64, (size_t)2 * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS);
     } else {
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((wgrad_kernel<float, 2, 64>), grid, dim3(256), lds, s, a);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YMI_WG_LAUNCH(float, 64, lds);
     }
+#undef YMI_WG_LAUNCH
     ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");
     const int64_t elems = (int64_t)a.CoutP * a.NG;
