@@ -395,6 +395,61 @@ def test_rccl_single_rank_bucketed_allreduce():
     assert total == float(sum(range(1 << 20)))
 
 
+def _rccl_split_worker(port, q):
+    import os
+
+    import torch.distributed as dist
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    from improving_yolov8_cbam_swinblock_amd.engine.trainer import TrainStep, synthetic_batch
+    from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
+
+    d = torch.device("cuda", 0)
+    probe = ("model.0.conv.weight", "model.7.attn.in_proj_weight", "model.22.cv2.bn.weight", "model.26.cv3.0.2.bias")
+    res = {}
+    for mode in ("eager", "split"):
+        torch.manual_seed(0)
+        model = DetectionModel("yolov8s.yaml", ch=3, nc=1).to(d)
+        step = TrainStep(model, world_size=1, lr=0.01, graph=False if mode == "eager" else "split")
+        batch = synthetic_batch(4, 320, d, 1)
+        out = [step(batch).float().cpu().clone() for _ in range(9 if mode == "eager" else 6)]
+        torch.cuda.synchronize()
+        sd = model.state_dict()
+        res[mode] = (torch.stack(out), {k: sd[k].detach().float().cpu().clone() for k in probe})
+        issued = sum(1 for _ in step.buckets.buckets)
+        del step, model
+    q.put((res["eager"][0][3:9].tolist(), res["split"][0].tolist(),
+           {k: float((res["split"][1][k] - res["eager"][1][k]).norm() / res["eager"][1][k].norm().clamp(min=1e-9)) for k in probe}, issued))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_graph_schedule_with_rccl_between_the_graphs():
+    """the several-rank schedule (G1 -> all_reduce(bucket 0) -> G2 -> all_reduce(bucket 1) -> wait -> G3) with REAL RCCL calls between the
+    replayed graphs: a world-size-1 nccl process group on the box's one GPU, so every collective is the identity, but the captures run
+    beside RCCL's watchdog thread, the async work objects are waited on by the update graph's stream, and the flat buckets are the
+    buffers RCCL reads and writes.  Losses and parameters must follow the eager step's (replay i = eager step i + 3)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    proc = ctx.Process(target=_rccl_split_worker, args=(port, q))
+    proc.start()
+    eager, split, errs, nb = q.get(timeout=600)
+    proc.join(120)
+    assert nb == 2
+    torch.testing.assert_close(torch.tensor(split), torch.tensor(eager), rtol=2e-2, atol=2e-2)
+    assert all(e < 5e-3 for e in errs.values()), errs
+
+
 def test_profile_table_lists_every_layer():
     """utils/profile.py: the per-module forward / backward table (reference torch_utils.py:792-870 reporting format)."""
     from improving_yolov8_cbam_swinblock_amd.nn.tasks import DetectionModel
