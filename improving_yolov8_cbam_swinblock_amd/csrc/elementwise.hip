@@ -558,7 +558,7 @@ static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const fl
     // up to one resident round of blocks, i.e. 1-2 pixels per thread
     int64_t gb = (P + (int64_t)rows * ew_ppt() - 1) / ((int64_t)rows * ew_ppt());
     if (gb < 1024) gb = (P + rows - 1) / rows < 1024 ? (P + rows - 1) / rows : 1024;
-    if (gb > ew_cap()) gb = ew_cap();  // default 2048: one resident round of 256-thread blocks on 256 CUs
+    if (gb > ew_cap()) gb = ew_cap();  // default 1024: four 256-thread workgroups per CU (runtime.hip)
     gb = (gb + 7) / 8 * 8;             // the same number of workgroups on every XCD
     const int64_t span = ymi_xcd_span_arg(P);
     dim3 g((unsigned)gb), b(256);

@@ -229,14 +229,17 @@ static int pow2_ge(int v) {
 // returns number of stage-1 blocks; partials must hold blocks*2*C floats.  A block's 256 threads cover 256 / (C/4) pixel rows at a
 // time and walk their pixels four per trip; on the small maps that walk is a chain of dependent HBM round trips (a 13 MB tensor
 // with 200 blocks of 64 pixels took 20 us at C = 512: 8 trips per thread), so a block gets one trip's worth of pixels
-// (>= 16) until the 1024-block cap - the large maps are unchanged.
+// (>= 16) until the block cap.  The cap is 512 = two workgroups per CU since round 4 (swept inside the step: 1024 was the isolated optimum
+// and 0.17 ms/step slower there, 2048 slower still; 640 / 768 leave an uneven second round; profiles/r04_ew_grid_sweep.txt): half the
+// partial rows for the final pass, and the pass shares the chip with nothing.
 static int reduce_blocks(int64_t P, int C) {
     const int tg = pow2_ge(C / 4) > 256 ? 256 : pow2_ge(C / 4);
     int64_t ppb = (int64_t)(256 / tg) * 4;
     if (ppb < 16) ppb = 16;
     if (ppb > 64) ppb = 64;
     int64_t b = (P + ppb - 1) / ppb;
-    if (b > 1024) b = 1024;
+    static const int rcap = getenv("YMI_RED_CAP") ? atoi(getenv("YMI_RED_CAP")) : 512;
+    if (b > rcap) b = rcap;
     if (b < 1) b = 1;
     return (int)((b + 7) / 8 * 8);  // the same number of workgroups on every XCD (chan_reduce_kernel walks XCD-owned pixel ranges)
 }

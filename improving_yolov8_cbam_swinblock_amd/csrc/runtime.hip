@@ -36,8 +36,12 @@ const void* ymi_zero_page() {
     return cached_ptr;
 }
 
-int ew_ppt() { return 8; }     // pixels per thread the elementwise passes aim for (round-1 sweep)
-int ew_cap() { return 2048; }  // their workgroup cap
+// Grid sizing of the streaming BatchNorm passes (affine + SiLU, backward apply), swept INSIDE the training step in round 4
+// (profiles/r04_ew_grid_sweep.txt; the round-1 values 8 / 2048 came from isolated launches): one resident round of four 256-thread
+// workgroups per CU, each thread walking up to 32 pixels, is 0.2 ms/step faster than eight per CU - fewer, longer workgroups amortise
+// the coefficient loads and the launch ramp, and the half-empty SIMDs do not matter to passes that wait on HBM.
+int ew_ppt() { static const int v = getenv("YMI_EW_PPT") ? atoi(getenv("YMI_EW_PPT")) : 32; return v; }    // pixels per thread the passes aim for
+int ew_cap() { static const int v = getenv("YMI_EW_CAP") ? atoi(getenv("YMI_EW_CAP")) : 1024; return v; }  // their workgroup cap
 
 // the span argument of the kernels that walk XCD-owned pixel ranges (common.h).  YMI_XCD_SHIFT=k (diagnostic knob, default 0) makes those
 // kernels work on the range of XCD (x + k) % 8 instead of their own - the anti-affine arrangement a same-box A/B measures against.
