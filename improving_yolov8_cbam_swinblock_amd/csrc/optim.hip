@@ -9,6 +9,9 @@
 //     or, hyper[14] = 1 / 2, torch.optim.AdamW / Adam (the reference's 'AdamW' / 'Adam' branches, trainer.py:829-830, which
 //     'auto' picks for short runs, :812): decoupled decay p *= 1 - lr*wd (Adam: g += wd*p), m = lerp(m, g, 1-b1),
 //     v = b2*v + (1-b2)*g*g, p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps); t counted on the device by pass 2.
+//     hyper[14] = 3 .. 6: the remaining branches of build_optimizer (trainer.py:827-832) with torch's default hyper-parameters -
+//     Adamax (exp_inf = max(b2*exp_inf, |g| + eps)), NAdam (Nesterov momentum schedule mu_t, its running product kept in the state),
+//     RAdam (variance rectification once rho_t > 5), RMSprop(momentum) - each one straight-line body of the same pass.
 //
 // HBM-bound: 28 B per parameter (p, g, buf, ema read; p, buf, ema written; Adam: 36 B with the second moment).  No torch.stack / foreach chains: every
 // operand is addressed through a device table built once (parameters, momentum and EMA buffers never move); the gradient
@@ -30,16 +33,20 @@ struct GradPtrs {
 
 // hyper layout (floats): [0..2] lr of group 0..2, [3..5] weight decay of group 0..2, [6] momentum, [7] max_norm,
 //                        [8] ema decay, [9] ema tau, [10] nesterov (0/1), [11] grad scale (1/world),
-//                        [12] beta2, [13] eps, [14] rule (0 SGD, 1 AdamW, 2 Adam), [15] 1 - beta2, [16] 1 - beta1 (the host's
-//                        double differences, as torch passes them), [17..19] unused                ([6] is beta1 for Adam)
+//                        [12] beta2 (RMSprop: alpha), [13] eps, [14] rule (0 SGD, 1 AdamW, 2 Adam, 3 Adamax, 4 NAdam, 5 RAdam, 6 RMSprop),
+//                        [15] 1 - beta2, [16] 1 - beta1 (the host's double differences, as torch passes them), [17] NAdam's
+//                        momentum_decay, [18] / [19] float32 tails of beta1 / momentum_decay (NAdam)                                  ([6] is beta1 for the Adam family)
 // state layout: float clip, float total_norm, float ema_d, float one_minus_d, int64 updates, int64 steps (optimizer steps
-//               taken: Adam's t), float 1/(1-b1^t), float sqrt(1-b2^t)
+//               taken: Adam's t), float 1/(1-b1^t), float sqrt(1-b2^t), float c0..c3 (per-step scalars of rules 4 / 5), double mu_product (NAdam)
 struct OptState {
     float clip, norm, ema_d, ema_1md;
     long long updates;
     long long steps;
     float inv_bc1, bc2_sqrt;
+    float c0, c1, c2, c3;
+    double mu_product;
 };
+static_assert(sizeof(OptState) == 64, "OptState is the 64-byte state buffer engine/optim.py allocates");
 
 __global__ __launch_bounds__(256) void opt_sumsq_kernel(const ymi_opt_entry* __restrict__ tab, const int2* __restrict__ chunks, int first_tensor, GradPtrs gp,
                                                         const float* __restrict__ hyper, float* __restrict__ part) {
@@ -98,14 +105,42 @@ __global__ __launch_bounds__(256) void opt_finalize_kernel(const float* __restri
         st->steps = t;
         if (hyper[14] != 0.f) {
             // (the betas are rebuilt from their float32 COMPLEMENTS: 1 - 0.999f is off by 1.3e-5 relative, 1 - float(0.001) by 5e-8)
-            st->inv_bc1 = (float)(1.0 / (1.0 - pow(1.0 - (double)hyper[16], (double)t)));
-            st->bc2_sqrt = (float)sqrt(1.0 - pow(1.0 - (double)hyper[15], (double)t));
+            const double b1 = 1.0 - (double)hyper[16], b2 = 1.0 - (double)hyper[15];
+            const double bc1 = 1.0 - pow(b1, (double)t), bc2 = 1.0 - pow(b2, (double)t);
+            st->inv_bc1 = (float)(1.0 / bc1);
+            st->bc2_sqrt = (float)sqrt(bc2);
+            const int rule = (int)hyper[14];
+            if (rule == 4) {
+                // torch.optim.NAdam: mu_t = beta1 * (1 - 0.5 * 0.96 ** (t * momentum_decay)), mu_product *= mu_t (Python floats)
+                // beta1 and momentum_decay to double precision (float32 head + tail: hyper[6] + hyper[18], hyper[17] + hyper[19]) - mu_product is
+                // a running product that torch rounds to float32 every step, and a 1e-9 error of beta1 flips one of those roundings within ten steps
+                const double b1x = (double)hyper[6] + (double)hyper[18], md = (double)hyper[17] + (double)hyper[19];
+                const double mu = b1x * (1.0 - 0.5 * pow(0.96, (double)t * md)), mu_next = b1x * (1.0 - 0.5 * pow(0.96, (double)(t + 1) * md));
+                // (torch keeps mu_product as a float32 state tensor and multiplies it in place: one float32 rounding per step)
+                const float mpf = (t == 1 ? 1.0f : (float)st->mu_product) * (float)mu;
+                const double mp = (double)mpf;
+                st->mu_product = mp;
+                st->c0 = (float)((1.0 - mu) / (1.0 - mp));            // weight of grad / denom
+                st->c1 = (float)(mu_next / (1.0 - mp * mu_next));     // weight of exp_avg / denom
+                st->c2 = (float)bc2;                                  // denom = sqrt(exp_avg_sq / bias_correction2) + eps
+            } else if (rule == 5) {
+                // torch.optim.RAdam: rho_t = rho_inf - 2 t beta2^t / (1 - beta2^t); rectified step once rho_t > 5
+                const double rho_inf = 2.0 / (1.0 - b2) - 1.0;
+                const double rho_t = rho_inf - 2.0 * (double)t * pow(b2, (double)t) / bc2;
+                if (rho_t > 5.0) {
+                    st->c0 = (float)sqrt((rho_t - 4.0) * (rho_t - 2.0) * rho_inf / ((rho_inf - 4.0) * (rho_inf - 2.0) * rho_t));
+                    st->c1 = 1.0f;
+                } else {
+                    st->c0 = 1.0f;
+                    st->c1 = 0.0f;
+                }
+            }
         }
     }
 }
 
 // MODE 0: parameters with gradients (update + EMA);  MODE 1: EMA only (buffers, frozen parameters)
-// RULE 0: SGD-momentum; 1: AdamW; 2: Adam (a compile-time parameter: one straight-line body per rule)
+// RULE 0: SGD-momentum; 1: AdamW; 2: Adam; 3: Adamax; 4: NAdam; 5: RAdam; 6: RMSprop (a compile-time parameter: one straight-line body per rule)
 template <int MODE, int RULE>
 __global__ __launch_bounds__(256) void opt_update_kernel(const ymi_opt_entry* __restrict__ tab, const int2* __restrict__ chunks, int first_tensor, GradPtrs gp,
                                                          const float* __restrict__ hyper, const OptState* __restrict__ st) {
@@ -120,6 +155,7 @@ __global__ __launch_bounds__(256) void opt_update_kernel(const ymi_opt_entry* __
     const int64_t end = base + OPT_CHUNK < e.numel ? base + OPT_CHUNK : e.numel;
     const float d = st->ema_d, omd = st->ema_1md;
     float lr = 0.f, wd = 0.f, mom = 0.f, gscale = 0.f, b2 = 0.f, eps = 0.f, step_size = 0.f, bc2s = 1.f, omb1 = 0.f, omb2 = 0.f;
+    float c0 = 0.f, c1 = 0.f, c2 = 1.f, ibc1 = 1.f;
     bool nest = false;
     if (MODE == 0 && g) {
         const int grp = e.group;
@@ -135,13 +171,40 @@ __global__ __launch_bounds__(256) void opt_update_kernel(const ymi_opt_entry* __
             omb1 = hyper[16];
             step_size = lr * st->inv_bc1;
             bc2s = st->bc2_sqrt;
+            ibc1 = st->inv_bc1;
+            c0 = st->c0; c1 = st->c1; c2 = st->c2;
         }
     }
     constexpr bool adam = RULE != 0;
     const float decay_mul = 1.f - lr * wd;
     auto one = [&](float pv, float gv, float bv, float sv, float ev, float& po, float& bo, float& so, float& eo) {
         so = sv;
-        if (MODE == 0 && adam && g) {
+        if (MODE == 0 && RULE >= 3 && g) {
+            float gr = gv * gscale;
+            if (wd != 0.f) gr = gr + wd * pv;                // grad.add(param, alpha=weight_decay)
+            if (RULE == 3) {                                 // torch.optim.Adamax
+                bo = bv + (gr - bv) * omb1;                  // exp_avg.lerp_(grad, 1 - beta1)
+                so = fmaxf(sv * b2, fabsf(gr) + eps);        // exp_inf = max(exp_inf * beta2, |grad| + eps)
+                po = pv - step_size * (bo / so);             // param.addcdiv_(exp_avg, exp_inf, value=-lr / bias_correction1)
+            } else if (RULE == 4) {                          // torch.optim.NAdam
+                bo = bv + (gr - bv) * omb1;
+                so = sv * b2 + omb2 * gr * gr;
+                const float denom = sqrtf(so / c2) + eps;    // exp_avg_sq.div(bias_correction2).sqrt().add_(eps)
+                const float p1 = pv - (lr * c0) * (gr / denom);   // param.addcdiv_(grad, denom, value=-lr (1 - mu) / (1 - mu_product))
+                po = p1 - (lr * c1) * (bo / denom);               // param.addcdiv_(exp_avg, denom, value=-lr mu_next / (1 - mu_product mu_next))
+            } else if (RULE == 5) {                          // torch.optim.RAdam
+                bo = bv + (gr - bv) * omb1;
+                so = sv * b2 + omb2 * gr * gr;
+                const float bce = bo * ibc1;                 // exp_avg / bias_correction1
+                if (c1 != 0.f) po = pv - ((bce * lr) * (bc2s / (sqrtf(so) + eps))) * c0;  // bias_corrected_exp_avg * lr * adaptive * rect
+                else po = pv - bce * lr;
+            } else {                                         // torch.optim.RMSprop(momentum > 0), alpha = b2
+                so = sv * b2 + omb2 * gr * gr;               // square_avg.mul_(alpha).addcmul_(grad, grad, value=1 - alpha)
+                const float avg = sqrtf(so) + eps;
+                bo = bv * mom + gr / avg;                    // buf.mul_(momentum).addcdiv_(grad, avg)
+                po = pv - lr * bo;
+            }
+        } else if (MODE == 0 && adam && g) {
             float gr = gv * gscale;
             float pw = pv;
             if (RULE == 1) pw = pv * decay_mul;             // AdamW: param.mul_(1 - lr * weight_decay)
@@ -241,7 +304,7 @@ extern "C" int ymi_opt_update(const ymi_opt_entry* table, const int32_t* chunk_m
                               const float* const* host_grads, const float* hyper, const void* state, int32_t rule, void* stream) {
     int rc = opt_check(table, chunk_map, first_tensor, n_tensors, n_chunks, hyper, const_cast<void*>(state), "opt_update");
     if (rc) return rc;
-    YMI_CHECK_ARG(rule >= 0 && rule <= 2, "opt_update: rule 0 (SGD), 1 (AdamW) or 2 (Adam)");
+    YMI_CHECK_ARG(rule >= 0 && rule <= 6, "opt_update: rule 0 (SGD), 1 (AdamW), 2 (Adam), 3 (Adamax), 4 (NAdam), 5 (RAdam) or 6 (RMSprop)");
     GradPtrs gp{};
     hipStream_t s = (hipStream_t)stream;
     const dim3 grid((unsigned)n_chunks), block(256);
@@ -251,7 +314,11 @@ extern "C" int ymi_opt_update(const ymi_opt_entry* table, const int32_t* chunk_m
         for (int i = 0; i < n_tensors; ++i) gp.g[i] = host_grads[i];
         if (rule == 0) hipLaunchKernelGGL((opt_update_kernel<0, 0>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
         else if (rule == 1) hipLaunchKernelGGL((opt_update_kernel<0, 1>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
-        else hipLaunchKernelGGL((opt_update_kernel<0, 2>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
+        else if (rule == 2) hipLaunchKernelGGL((opt_update_kernel<0, 2>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
+        else if (rule == 3) hipLaunchKernelGGL((opt_update_kernel<0, 3>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
+        else if (rule == 4) hipLaunchKernelGGL((opt_update_kernel<0, 4>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
+        else if (rule == 5) hipLaunchKernelGGL((opt_update_kernel<0, 5>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
+        else hipLaunchKernelGGL((opt_update_kernel<0, 6>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
     } else {
         hipLaunchKernelGGL((opt_update_kernel<1, 0>), grid, block, 0, s, table, cm, first_tensor, gp, hyper, st);
     }

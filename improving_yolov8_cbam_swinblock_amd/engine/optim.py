@@ -82,7 +82,7 @@ class ModelEMA:
 class FusedSGD:
     """SGD(momentum, nesterov) over the reference's three parameter groups + gradient clipping (+ EMA), fused."""
 
-    RULE = 0  # csrc/optim.hip hyper[14]: 0 SGD-momentum, 1 AdamW, 2 Adam
+    RULE = 0  # csrc/optim.hip hyper[14]: 0 SGD-momentum, 1 AdamW, 2 Adam, 3 Adamax, 4 NAdam, 5 RAdam, 6 RMSprop
 
     def __init__(self, model, lr=0.01, momentum=0.937, decay=5e-4, nesterov=True, max_norm=10.0, ema=None, sgd=True):
         self.model = model
@@ -161,10 +161,13 @@ class FusedSGD:
         self._cmap = torch.tensor(cmap, dtype=torch.int32).reshape(-1, 2).contiguous().to(dev)
         self.n_grad_chunks = first_chunk_of[self.n_sgd] if self.sgd else len(cmap)
         self._partials = torch.zeros(max(self.n_grad_chunks, 1), dtype=torch.float32, device=dev)
-        steps = int(self._state.view(torch.int64)[3]) if getattr(self, "_state", None) is not None else 0  # rebuild: keep Adam's t
+        had = getattr(self, "_state", None) is not None
+        steps = int(self._state.view(torch.int64)[3]) if had else 0  # rebuild: keep Adam's t ...
+        mu_product = float(self._state.view(torch.float64)[7]) if had else 0.0  # ... and NAdam's running product
         self._state = torch.zeros(64, dtype=torch.uint8, device=dev)
         if steps:
             self._state.view(torch.int64)[3] = steps
+            self._state.view(torch.float64)[7] = mu_product
         self._dev_updates = 0  # host mirror of the device-side EMA update counter (_state[2]); see _sync_updates
         self._hyper = torch.zeros(20, dtype=torch.float32, device=dev)
         self._hyper_host = None  # a fresh device array: the next sync_hyper() must fill it
@@ -180,7 +183,7 @@ class FusedSGD:
         ema = self.ema
         host = [g[0]["lr"], g[1]["lr"], g[2]["lr"], g[0]["weight_decay"], g[1]["weight_decay"], g[2]["weight_decay"], self._beta1(),
                 self.max_norm, ema.decay_max if ema is not None else 0.0, ema.tau if ema is not None else 1.0, 1.0 if g[0].get("nesterov") else 0.0,
-                1.0 / self.world, *self._rule_hyper(), 0.0, 0.0, 0.0]
+                1.0 / self.world, *self._rule_hyper(), *self._rule_extra()]
         host = [float(v) for v in host]
         if host != self._hyper_host:
             self._hyper.copy_(torch.tensor(host, dtype=torch.float32))
@@ -196,6 +199,10 @@ class FusedSGD:
     def _rule_hyper(self):
         """hyper[12..16]: beta2, eps, rule, 1 - beta2, 1 - beta1."""
         return 0.0, 0.0, float(self.RULE), 0.0, 0.0
+
+    def _rule_extra(self):
+        """hyper[17..19]."""
+        return 0.0, 0.0, 0.0
 
     def _sync_updates(self):
         """the kernel derives the EMA decay from a DEVICE counter; `ema.updates` is the host's view of it.  A caller may set
@@ -302,6 +309,7 @@ class FusedAdamW(FusedSGD):
     state_dict() / load_state_dict() use torch.optim.Adam's layout (step, exp_avg, exp_avg_sq per parameter)."""
 
     RULE = 1
+    SECOND_KEY = "exp_avg_sq"  # (Adamax: exp_inf)
 
     def __init__(self, model, lr=0.001, betas=(0.9, 0.999), eps=1e-8, decay=5e-4, max_norm=10.0, ema=None, decoupled=True):
         super().__init__(model, lr=lr, momentum=betas[0], decay=decay, nesterov=False, max_norm=max_norm, ema=ema)
@@ -338,11 +346,14 @@ class FusedAdamW(FusedSGD):
             ids = []
             for p in grp["params"]:
                 if t > 0 and p.requires_grad:  # torch creates a parameter's state at its first step with a gradient
-                    state[idx] = {"step": torch.tensor(t), "exp_avg": self.momentum[idx], "exp_avg_sq": self.second[idx]}
+                    state[idx] = {"step": torch.tensor(t), "exp_avg": self.momentum[idx], self.SECOND_KEY: self.second[idx]}
+                    if self.RULE == 4:
+                        state[idx]["mu_product"] = torch.tensor(self.mu_product())
                 ids.append(idx)
                 idx += 1
+            extra = {"fused": None, "decoupled_weight_decay": self.RULE == 1} if self.RULE in (1, 2) else {}
             groups.append({k: v for k, v in grp.items() if k != "params"} | {"params": ids, "maximize": False, "foreach": None, "capturable": False,
-                                                                             "differentiable": False, "fused": None, "decoupled_weight_decay": self.RULE == 1})
+                                                                             "differentiable": False} | extra)
         return {"state": state, "param_groups": groups}
 
     def load_state_dict(self, sd):
@@ -355,6 +366,111 @@ class FusedAdamW(FusedSGD):
         steps = 0
         for idx, st in sd["state"].items():
             self.momentum[int(idx)].copy_(st["exp_avg"].to(torch.float32))
-            self.second[int(idx)].copy_(st["exp_avg_sq"].to(torch.float32))
+            self.second[int(idx)].copy_(st[self.SECOND_KEY].to(torch.float32))
             steps = max(steps, int(float(st["step"])))
+            if self.RULE == 4 and "mu_product" in st:
+                self._state.view(torch.float64)[7] = float(st["mu_product"])
         self._state.view(torch.int64)[3] = steps  # one t for every parameter (they step together)
+
+
+class FusedAdamax(FusedAdamW):
+    """torch.optim.Adamax (reference trainer.py:829-830 with name 'Adamax'): exp_inf = max(beta2 * exp_inf, |g| + eps),
+    p -= lr / (1 - beta1^t) * exp_avg / exp_inf; weight decay added to the gradient.  State layout: step, exp_avg, exp_inf."""
+
+    SECOND_KEY = "exp_inf"
+
+    def __init__(self, model, lr=0.002, betas=(0.9, 0.999), eps=1e-8, decay=5e-4, max_norm=10.0, ema=None):
+        super().__init__(model, lr=lr, betas=betas, eps=eps, decay=decay, max_norm=max_norm, ema=ema, decoupled=False)
+        self.RULE = 3
+        for grp in self.param_groups:
+            grp.pop("amsgrad", None)
+
+
+class FusedNAdam(FusedAdamW):
+    """torch.optim.NAdam (momentum_decay 4e-3, weight decay added to the gradient): the Nesterov momentum schedule
+    mu_t = beta1 (1 - 0.5 * 0.96^(t * momentum_decay)) and its running product are kept on the device.  State: step, mu_product, exp_avg, exp_avg_sq."""
+
+    def __init__(self, model, lr=0.002, betas=(0.9, 0.999), eps=1e-8, decay=5e-4, max_norm=10.0, ema=None, momentum_decay=4e-3):
+        super().__init__(model, lr=lr, betas=betas, eps=eps, decay=decay, max_norm=max_norm, ema=ema, decoupled=False)
+        self.RULE = 4
+        for grp in self.param_groups:
+            grp.pop("amsgrad", None)
+            grp.update(momentum_decay=float(momentum_decay), decoupled_weight_decay=False)
+
+    def _rule_extra(self):
+        """momentum_decay, and the float32 tails of beta1 and momentum_decay (the device rebuilds both to double precision)."""
+        f32 = lambda v: float(torch.tensor(v, dtype=torch.float32))
+        b1, md = float(self.param_groups[0]["betas"][0]), float(self.param_groups[0]["momentum_decay"])
+        return md, b1 - f32(b1), md - f32(md)
+
+    def mu_product(self):
+        return float(self._state.view(torch.float64)[7]) if self.steps_taken() else 1.0
+
+
+class FusedRAdam(FusedAdamW):
+    """torch.optim.RAdam (weight decay added to the gradient): the variance-rectified step once rho_t > 5, plain bias-corrected momentum before."""
+
+    def __init__(self, model, lr=0.001, betas=(0.9, 0.999), eps=1e-8, decay=5e-4, max_norm=10.0, ema=None):
+        super().__init__(model, lr=lr, betas=betas, eps=eps, decay=decay, max_norm=max_norm, ema=ema, decoupled=False)
+        self.RULE = 5
+        for grp in self.param_groups:
+            grp.pop("amsgrad", None)
+            grp.update(decoupled_weight_decay=False)
+
+
+class FusedRMSprop(FusedSGD):
+    """torch.optim.RMSprop(lr, momentum=momentum) as the reference builds it (trainer.py:831-832): alpha 0.99, eps 1e-8, not centered;
+    square_avg = alpha * square_avg + (1 - alpha) g^2, buf = momentum * buf + g / (sqrt(square_avg) + eps), p -= lr * buf.
+    State layout: step, square_avg, momentum_buffer."""
+
+    RULE = 6
+
+    def __init__(self, model, lr=0.01, momentum=0.937, alpha=0.99, eps=1e-8, decay=5e-4, max_norm=10.0, ema=None):
+        super().__init__(model, lr=lr, momentum=momentum, decay=decay, nesterov=False, max_norm=max_norm, ema=ema)
+        for grp in self.param_groups:
+            for k in ("nesterov", "dampening"):
+                grp.pop(k)
+            grp.update(alpha=float(alpha), eps=float(eps), centered=False)
+
+    def _beta1(self):
+        g = self.param_groups
+        if any(grp["momentum"] != g[0]["momentum"] or grp["alpha"] != g[0]["alpha"] or grp["eps"] != g[0]["eps"] for grp in g):
+            raise RuntimeError("FusedRMSprop: momentum / alpha / eps are shared by the three groups (as the reference sets them)")
+        return g[0]["momentum"]
+
+    def _rule_hyper(self):
+        g = self.param_groups[0]
+        return g["alpha"], g["eps"], float(self.RULE), 1 - g["alpha"], 0.0
+
+    def steps_taken(self):
+        return int(self._state.view(torch.int64)[3]) if self._table is not None else 0
+
+    def state_dict(self):
+        if self._table is None:
+            self._build()
+        t = float(self.steps_taken())
+        state, groups, idx = {}, [], 0
+        for grp in self.param_groups:
+            ids = []
+            for p in grp["params"]:
+                if t > 0 and p.requires_grad:
+                    state[idx] = {"step": torch.tensor(t), "square_avg": self.second[idx], "momentum_buffer": self.momentum[idx]}
+                ids.append(idx)
+                idx += 1
+            groups.append({k: v for k, v in grp.items() if k != "params"} | {"params": ids, "maximize": False, "foreach": None, "capturable": False,
+                                                                             "differentiable": False})
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        if self._table is None:
+            self._build()
+        for grp, saved in zip(self.param_groups, sd["param_groups"]):
+            for k in ("lr", "initial_lr", "momentum", "alpha", "eps", "weight_decay"):
+                if k in saved:
+                    grp[k] = saved[k]
+        steps = 0
+        for idx, st in sd["state"].items():
+            self.second[int(idx)].copy_(st["square_avg"].to(torch.float32))
+            self.momentum[int(idx)].copy_(st["momentum_buffer"].to(torch.float32))
+            steps = max(steps, int(float(st["step"])))
+        self._state.view(torch.int64)[3] = steps

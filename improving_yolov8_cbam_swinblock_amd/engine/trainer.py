@@ -8,7 +8,7 @@ import torch.nn as nn
 
 from .. import ops
 from .ddp import GradientBuckets
-from .optim import FusedAdamW, FusedSGD, ModelEMA
+from .optim import FusedAdamax, FusedAdamW, FusedNAdam, FusedRAdam, FusedRMSprop, FusedSGD, ModelEMA
 
 # weight-gradient GEMMs on a second stream during backward (ops.async_wgrad) in EAGER steps; YMI_WGRAD_STREAM=0 keeps
 # one stream.  Graph-replayed steps stay single-stream: measured no wall-time gain there, and concurrent kernels stretch
@@ -21,9 +21,10 @@ def build_optimizer(model, name="SGD", lr=0.01, momentum=0.937, decay=5e-4, ema=
     weights, norm weights) and
       * 'SGD'  (:832-833)  nesterov momentum, as the fused HIP step FusedSGD;
       * 'AdamW' / 'Adam' (:829-830)  betas = (momentum, 0.999), as FusedAdamW;
+      * 'Adamax' / 'NAdam' / 'RAdam' (:829-830) and 'RMSProp' (:831-832) with torch's default hyper-parameters, as FusedAdamax / FusedNAdam /
+        FusedRAdam / FusedRMSprop (the same three launches, another compiled rule);
       * 'auto' (:804-813)  SGD(lr 0.01, momentum 0.9) for more than 10000 iterations, else AdamW(lr = round(0.002 * 5 / (4 + nc), 6),
         beta1 0.9) - the caller's lr / momentum are ignored, as in the reference.
-    The reference's other names (Adamax, NAdam, RAdam, RMSProp) have no fused step here and raise NotImplementedError.
     The gradients the step is handed are already the mean over ranks (GradientBuckets.finish divides once), so the step itself
     never scales by the world size."""
     if name == "auto":
@@ -37,7 +38,12 @@ def build_optimizer(model, name="SGD", lr=0.01, momentum=0.937, decay=5e-4, ema=
         return FusedSGD(model, lr=lr, momentum=momentum, decay=decay, nesterov=True, max_norm=10.0, ema=ema)
     if name in ("AdamW", "Adam"):
         return FusedAdamW(model, lr=lr, betas=(momentum, 0.999), decay=decay, max_norm=10.0, ema=ema, decoupled=name == "AdamW")
-    raise NotImplementedError(f"optimizer {name!r}: the fused MI355X step implements SGD, AdamW and Adam (reference trainer.py:827-840)")
+    if name in ("Adamax", "NAdam", "RAdam"):  # trainer.py:829-830: getattr(optim, name)(g[2], lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+        cls = {"Adamax": FusedAdamax, "NAdam": FusedNAdam, "RAdam": FusedRAdam}[name]
+        return cls(model, lr=lr, betas=(momentum, 0.999), decay=decay, max_norm=10.0, ema=ema)
+    if name == "RMSProp":  # trainer.py:831-832: optim.RMSprop(g[2], lr=lr, momentum=momentum)
+        return FusedRMSprop(model, lr=lr, momentum=momentum, decay=decay, max_norm=10.0, ema=ema)
+    raise NotImplementedError(f"optimizer {name!r} is not one of the reference's (trainer.py:827-840)")
 
 
 def synthetic_batch(batch, imgsz, device, seed, boxes_per_image=4):

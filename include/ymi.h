@@ -365,22 +365,23 @@ int ymi_detect_decode(int32_t nl, const ymi_tensor* box_maps, const ymi_tensor* 
  *              momentum / ema may be NULL (no momentum buffer: EMA-only entry; no ema: EMA not attached)
  *   chunk_map  [n_chunks][2] int32 (tensor index, chunk index): one workgroup per ymi_opt_chunk_elems() elements
  *   hyper      [20] float on the device: lr[3], weight_decay[3], momentum (Adam: beta1), max_norm (<= 0: no clipping), ema decay,
- *              ema tau, nesterov (0/1), gradient scale (1 / world size), beta2, eps, rule (0 SGD-momentum - reference
- *              trainer.py:832-833; 1 AdamW, 2 Adam - trainer.py:829-830), 1 - beta2, 1 - beta1 (differences taken in double on the
- *              host, as torch passes them), 3 unused
+ *              ema tau, nesterov (0/1), gradient scale (1 / world size), beta2 (RMSprop: alpha), eps, rule (0 SGD-momentum - reference
+ *              trainer.py:832-833; 1 AdamW, 2 Adam, 3 Adamax, 4 NAdam, 5 RAdam - trainer.py:829-830; 6 RMSprop - :831), 1 - beta2,
+ *              1 - beta1 (differences taken in double on the host, as torch passes them), NAdam's momentum_decay, the float32 tails of beta1 and momentum_decay (NAdam)
  *   state      64 bytes on the device, zero before the first step: float clip, float total_norm, float ema_d, float 1-ema_d,
- *              int64 updates, int64 steps (Adam's t), float 1/(1-beta1^t), float sqrt(1-beta2^t)
+ *              int64 updates, int64 steps (Adam's t), float 1/(1-beta1^t), float sqrt(1-beta2^t), 4 floats of per-step scalars
+ *              (NAdam's two weights and bias correction, RAdam's rectification), double mu_product (NAdam)
  * A launch covers tensors [first_tensor, first_tensor + n_tensors), n_tensors <= YMI_OPT_MAX_GRADS, whose chunks are the
  * n_chunks entries at chunk_map; host_grads[i] is the gradient of tensor first_tensor + i or NULL (no gradient this step). */
 #define YMI_OPT_MAX_GRADS 448
 typedef struct ymi_opt_entry {
     float* param;
-    float* momentum; /* SGD: momentum buffer; Adam / AdamW: exp_avg */
+    float* momentum; /* SGD / RMSprop: momentum buffer; Adam family: exp_avg */
     float* ema;
     int64_t numel;
     int32_t group;
     int32_t _pad;
-    float* second;   /* Adam / AdamW: exp_avg_sq; NULL for SGD and EMA-only entries */
+    float* second;   /* Adam / AdamW / NAdam / RAdam: exp_avg_sq; Adamax: exp_inf; RMSprop: square_avg; NULL for SGD and EMA-only entries */
     void* _pad2;
 } ymi_opt_entry;
 int64_t ymi_opt_chunk_elems(void);
@@ -393,6 +394,8 @@ int ymi_opt_grad_norm(const ymi_opt_entry* table, const int32_t* chunk_map, int3
 /* rule 0: g = grad*scale*clip (+ wd*p); buf = momentum*buf + g; g = nesterov ? g + momentum*buf : buf; p -= lr*g;
  * rule 1 / 2 (torch.optim.AdamW / Adam): p *= 1 - lr*wd (Adam: g += wd*p); m = m + (g-m)(1-beta1); v = beta2 v + (1-beta2) g g;
  *   p -= lr/(1-beta1^t) * m / (sqrt(v)/sqrt(1-beta2^t) + eps);
+ * rule 3 .. 6 (torch.optim.Adamax / NAdam / RAdam / RMSprop with momentum, torch's default hyper-parameters): the single-tensor
+ *   update of each, weight decay added to the gradient;
  * then ema = d*ema + (1-d)*p.  `rule` must equal hyper[14] (it selects the compiled kernel; pass 2 reads hyper[14] for the bias corrections).  host_grads == NULL: EMA-only pass over the given tensors (buffers, frozen parameters). */
 int ymi_opt_update(const ymi_opt_entry* table, const int32_t* chunk_map, int32_t first_tensor, int32_t n_tensors, int64_t n_chunks,
                    const float* const* host_grads, const float* hyper, const void* state, int32_t rule, void* stream);

@@ -13,7 +13,7 @@ import torch.nn as nn
 
 def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, name="SGD"):
     """trainer.py:814-843: g[2] biases (no decay) first, then add_param_group(g[0] weights, decay), (g[1] norm weights);
-    name: 'SGD' (:832-833) or 'AdamW' / 'Adam' (:829-830, betas = (momentum, 0.999))."""
+    name: 'SGD' (:832-833), 'AdamW' / 'Adam' / 'Adamax' / 'NAdam' / 'RAdam' (:829-830, betas = (momentum, 0.999)) or 'RMSProp' (:831-832)."""
     g = [], [], []  # frozen parameters ('.dfl', trainer.py:244-256) are grouped too: SGD skips tensors without a gradient
     bn = tuple(v for k, v in nn.__dict__.items() if "Norm" in k)
     for module_name, module in model.named_modules():
@@ -25,8 +25,10 @@ def build_optimizer(model, lr=0.01, momentum=0.937, decay=5e-4, name="SGD"):
                 g[1].append(param)
             else:
                 g[0].append(param)
-    if name in ("AdamW", "Adam"):
+    if name in ("AdamW", "Adam", "Adamax", "NAdam", "RAdam"):
         opt = getattr(torch.optim, name)(g[2], lr=lr, betas=(momentum, 0.999), weight_decay=0.0)
+    elif name == "RMSProp":
+        opt = torch.optim.RMSprop(g[2], lr=lr, momentum=momentum)
     else:
         opt = torch.optim.SGD(g[2], lr=lr, momentum=momentum, nesterov=True)
     opt.add_param_group({"params": g[0], "weight_decay": decay})
