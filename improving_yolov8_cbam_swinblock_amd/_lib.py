@@ -45,6 +45,8 @@ _TP = ctypes.POINTER(YmiTensor)
 _SIGNATURES = {
     "ymi_version": (_c_i32, []),
     "ymi_last_error": (ctypes.c_char_p, []),
+    "ymi_set_option": (_c_i32, [ctypes.c_char_p, _c_i64]),
+    "ymi_get_option": (_c_i64, [ctypes.c_char_p]),
     "ymi_profile_begin": (_c_i32, [_c_i64]),
     "ymi_profile_end": (_c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64)]),
     "ymi_profile_end_ex": (_c_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_c_i64),
@@ -87,6 +89,12 @@ _SIGNATURES = {
     "ymi_conv2d_bwd_data": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _vp]),
     "ymi_conv2d_bwd_data_add": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _TP, _TP, _TP, _vp]),
     "ymi_swin_mlp_fwd": (_c_i32, [_TP, _vp, _vp, _c_i64, _vp, _vp, _TP, _TP, _TP, _TP, _vp]),
+    "ymi_swin_ln_mlp_supported": (_c_i32, [_c_i64, _c_i64, _c_i32]),
+    "ymi_swin_ln_mlp_pack_elems": (_c_i64, [_c_i64, _c_i64]),
+    "ymi_swin_ln_mlp_pre_elems": (_c_i64, [_c_i64, _c_i64]),
+    "ymi_swin_ln_mlp_pack": (_c_i32, [_vp, _vp, _c_i64, _c_i64, _vp, _vp]),
+    "ymi_swin_ln_mlp_fwd": (_c_i32, [_TP, _vp, _vp, _c_f32, _vp, _vp, _vp, _c_i64, _TP, _vp, _vp, _vp, _TP, _vp]),
+    "ymi_swin_ln_mlp_bwd_data": (_c_i32, [_TP, _vp, _vp, _c_i64, _TP, _TP, _TP, _vp]),
     "ymi_swin_mlp_bwd_data": (_c_i32, [_TP, _vp, _TP, _TP, _vp, _TP, _TP, _TP, _vp]),
     "ymi_conv2d_bwd_weight": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_weight_workspace": (_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
@@ -270,3 +278,15 @@ def workspace(nbytes, device, tag="default"):
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _workspaces[key] = buf
     return buf
+
+
+def set_option(name, value):
+    """development option of the library (include/ymi.h: ymi_set_option; csrc/common.h lists the names).  Tests and A/B scripts only."""
+    check(lib().ymi_set_option(name.encode(), int(value)), "set_option")
+
+
+def get_option(name):
+    v = lib().ymi_get_option(name.encode())
+    if v < 0:
+        raise RuntimeError(f"unknown option {name!r}")
+    return int(v)

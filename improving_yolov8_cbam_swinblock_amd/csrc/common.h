@@ -42,10 +42,26 @@ static inline size_t ymi_esize(int dtype) { return dtype == YMI_BF16 ? 2 : 4; }
 static inline bool ymi_same_shape(const ymi_tensor* a, const ymi_tensor* b) {
     return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c;
 }
-// grid sizing of the streaming BatchNorm kernels (tuning knobs YMI_EW_PPT / YMI_EW_CAP): pixels each thread should get so
-// that its per-channel coefficient loads amortise, and the workgroup cap
-int ew_ppt();
-int ew_cap();
+// Development options (runtime.hip): named integers behind ymi_set_option / ymi_get_option - the "before" arm of a measured change, grid
+// sizes for in-step sweeps, forced code paths for tests.  Each starts at its default, or at the value of the environment variable
+// YMI_<NAME> when the process starts with one (tools/*.sh sweeps); production code never sets any.
+enum YmiOpt {
+    OPT_EW_PPT,           // streaming BatchNorm passes: pixels per thread aimed for (32)
+    OPT_EW_CAP,           // ... and their workgroup cap (1024)
+    OPT_RED_CAP,          // BatchNorm backward reduce: workgroup cap (512)
+    OPT_XCD_SHIFT,        // streaming passes work on XCD (x + k) % 8's pixels: the anti-affine arrangement (0)
+    OPT_ATTN_TILED,       // 1: tiled window attention for every window size (tests) (0)
+    OPT_WGRAD_BLOCKS,     // weight gradient: split-K workgroup target, 64-row tiles (1280)
+    OPT_WGRAD_BLOCKS128,  // ... 128-row tiles (768)
+    OPT_IGEMM_TILE_BM,    // force a GEMM tile (tools/conv_bench.py sweeps); 0: choose_tile
+    OPT_IGEMM_TILE_BN,
+    OPT_BN_TAIL,          // 1: BatchNorm backward's final pass inside the reduce kernel (last-arriver hand-off: measured slower,
+                          //    profiles/r05_bn_tail_ab.txt); 0 (default): its own launch
+    OPT_COUNT
+};
+int ymi_opt(int id);
+static inline int ew_ppt() { return ymi_opt(OPT_EW_PPT); }
+static inline int ew_cap() { return ymi_opt(OPT_EW_CAP); }
 // a 16-byte block of zeros in device memory (source of out-of-bounds im2col taps)
 const void* ymi_zero_page();
 
@@ -202,6 +218,45 @@ template <int ACT> __device__ __forceinline__ float act_grad(float x) {
 __device__ __forceinline__ float act_grad_rt(float x, int act) {
     return act == YMI_ACT_SILU ? silu_grad_f(x) : act == YMI_ACT_GELU ? gelu_grad_f(x) : 1.0f;
 }
+
+// ---- in-launch hand-offs between workgroups (round 5) ----------------------------------------------------------------------------
+// The per-XCD L2s are not coherent and a CU's L1 is never refreshed by another CU's stores, so a workgroup that consumes another
+// workgroup's bytes INSIDE a launch needs them written through and read past its L1.  The form used here (MI355X_MICROARCH.md,
+// "Valid forms", first table row; cdna_hip_programming.md Guideline 16 R1): every handed-off byte is stored with an agent-scope relaxed
+// atomic store (global_store ... sc1: write-through, no release fence), every storing wave drains with s_waitcnt vmcnt(0), the workgroup
+// meets at a barrier, ONE lane takes a ticket with an agent-scope relaxed fetch-add, and the workgroup whose add returned the last
+// ticket reads the bytes with agent-scope relaxed atomic loads (global_load ... sc1: past L1).  No __threadfence(), no buffer_wbl2, no
+// buffer_inv anywhere: round 4's form of the same idea (every thread of every workgroup fencing twice) cost 130 us per launch.
+// Results never depend on who arrives last: the combining workgroup sums fixed rows in fixed order.
+__device__ __forceinline__ void st_wt(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt2(float* p, float a, float b) {  // 8-byte aligned pair
+    const uint64_t v = (uint64_t)__builtin_bit_cast(uint32_t, a) | ((uint64_t)__builtin_bit_cast(uint32_t, b) << 32);
+    __hip_atomic_store(reinterpret_cast<uint64_t*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ld_wt(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double ld_wt(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void ld_wt2(const float* p, float& a, float& b) {
+    const uint64_t v = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a = __builtin_bit_cast(float, (uint32_t)v);
+    b = __builtin_bit_cast(float, (uint32_t)(v >> 32));
+}
+// Ticket: call from EVERY thread of the workgroup after the write-through stores.  `flag` is one LDS word nothing else uses until the
+// second barrier.  Returns (workgroup-uniform) whether this workgroup drew ticket `last`; that workgroup also resets the counter, so
+// counters are zero between launches (they start zero: __device__ storage, runtime.hip).
+__device__ __forceinline__ bool ticket_is_last(unsigned* counter, unsigned last, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's write-through stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (t == last) __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // every workgroup has drawn
+        *flag = t == last;
+    }
+    __syncthreads();
+    return *flag != 0;
+}
+// a slot of 64 ticket counters for one launch (host; round-robin over 1024 slots, zero between launches)
+unsigned* ymi_ticket_slot();
 
 // retire all but the N youngest vector-memory operations of this wave, then meet the workgroup: bytes written
 // to LDS by LDS-DMA (global_load_lds) are readable by other waves only after BOTH (counted wait, then barrier).

@@ -900,14 +900,11 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool bf16) 
     if (bf16 && cout >= 128 && ktot % 32 == 0 && blocks(256, 128) >= pp_env) {
         t.bm = 256; t.bn = 128; t.pp = true;
     }
-    static const char* tile_env = getenv("YMI_IGEMM_TILE");  // "bm,bn": force a tile (tools/conv_bench.py sweeps)
-    if (tile_env) {
-        int bm = 0, bn = 0;
-        if (sscanf(tile_env, "%d,%d", &bm, &bn) == 2 && (bn <= 32 ? cout <= 32 : true)) {
-            t.bm = bm;
-            t.bn = bn;
-            t.pp = bm == 256;
-        }
+    const int fbm = ymi_opt(OPT_IGEMM_TILE_BM), fbn = ymi_opt(OPT_IGEMM_TILE_BN);  // force a tile (tools/conv_bench.py sweeps)
+    if (fbm > 0 && fbn > 0 && (fbn <= 32 ? cout <= 32 : true)) {
+        t.bm = fbm;
+        t.bn = fbn;
+        t.pp = fbm == 256;
     }
     return t;
 }

@@ -22,9 +22,48 @@ struct GammaBeta2 {
     const float* beta;
     int split;
 };
+// coefficients of the BN backward apply pass, from the finished sums (one set per channel):
+//   z = x*a0 + a1 ;  draw = dy*act'(z)*c0 - x*c1 - c2
+struct BnCoefArgs {
+    const float* gamma;
+    const float* beta;
+    const float* mean;
+    const float* inv;
+    float inv_count;
+    float* coef;  // [5][C] or nullptr
+    GammaBeta2 g2;
+};
+__device__ __forceinline__ void bn_coef_write(const BnCoefArgs& bn, int C, int c, float s0, float s1) {
+    const bool second = bn.g2.split > 0 && c >= bn.g2.split;
+    const float* gp = second ? bn.g2.gamma : bn.gamma;
+    const float* bp = second ? bn.g2.beta : bn.beta;
+    const int pc = second ? c - bn.g2.split : c;
+    const float ga = gp ? gp[pc] : 1.0f, be = bp ? bp[pc] : 0.0f;
+    const float p0 = bn.inv[c], p1 = -bn.mean[c] * p0;
+    const float k1 = s0 * bn.inv_count, k2 = s1 * bn.inv_count;
+    bn.coef[0 * C + c] = p0 * ga;
+    bn.coef[1 * C + c] = p1 * ga + be;
+    bn.coef[2 * C + c] = ga * p0;
+    bn.coef[3 * C + c] = ga * p0 * p0 * k2;
+    bn.coef[4 * C + c] = ga * p0 * (k1 + p1 * k2);
+}
+// Tail of stage 1 (round 5): the workgroup that finishes LAST does stage 2 itself, so the separate final launch (a 1-16 workgroup kernel
+// at a dependent-launch latency, ~57 times a step) disappears.  Two levels, both deterministic (fixed rows in fixed order, whoever runs
+// them): the last workgroup of each of the 8 id classes (blockIdx.x & 7) sums that class's rows into xrows[class]; the last of those 8
+// sums the 8 rows and writes the results / the apply pass's coefficients.  The hand-off is common.h's write-through form: partial rows
+// and class rows leave by sc1 stores, one lane per workgroup draws a ticket, only the last arriver reads (sc1 loads).  Round 4 built this
+// with __threadfence() in every workgroup: 17.6 -> 148 us per launch (profiles/r04_bn_tail_ticket_ab.txt).  tickets == nullptr: no tail.
+struct ReduceTail {
+    unsigned* tickets;  // ncls + 1 counters (the last at [32]), zero between launches
+    int ncls;           // id classes: 32 or 8 (divides the grid)
+    double* xrows;      // [ncls][2][C]
+    float* out0;
+    float* out1;
+    BnCoefArgs bn;
+};
 template <typename T, int FN, int ACT>
 __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
-                                   const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part, GammaBeta2 g2) {
+                                   const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part, GammaBeta2 g2, ReduceTail tail) {
     extern __shared__ float red[];  // [rows][TG][8]
     const int rows = 256 / TG;
     const int tx = threadIdx.x % TG, ty = threadIdx.x / TG;
@@ -131,11 +170,72 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, i
                 s1[r] += o[4 + r];
             }
         }
+        float* r0 = part + ((int64_t)blockIdx.x * 2 + 0) * C + c0 + tx * 4;
+        float* r1 = part + ((int64_t)blockIdx.x * 2 + 1) * C + c0 + tx * 4;
+        if (tail.tickets) {  // (kernel argument: uniform) write-through: the last workgroup of the id class reads these rows in this launch
+            st_wt2(r0, s0[0], s0[1]);
+            st_wt2(r0 + 2, s0[2], s0[3]);
+            st_wt2(r1, s1[0], s1[1]);
+            st_wt2(r1 + 2, s1[2], s1[3]);
+        } else {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            part[((int64_t)blockIdx.x * 2 + 0) * C + c0 + tx * 4 + r] = s0[r];
-            part[((int64_t)blockIdx.x * 2 + 1) * C + c0 + tx * 4 + r] = s1[r];
+            for (int r = 0; r < 4; ++r) {
+                r0[r] = s0[r];
+                r1[r] = s1[r];
+            }
         }
+    }
+    if (tail.tickets == nullptr) return;
+    // ---- stage 2 by the last workgroups (host: one grid row, C <= 1024) -----------------------------------------------------------------
+    // NC id classes (blockIdx.x % NC; 32 when the grid allows, else 8): a class has gridDim.x / NC rows - 16 for the usual 512-row grid -
+    // so its last workgroup has ALL its loads in flight at once, and the last of the NC class leaders reads NC rows the same way
+    int* flag = reinterpret_cast<int*>(red);
+    const int NC = tail.ncls;
+    const int xg = blockIdx.x % NC, nbx = gridDim.x / NC;
+    if (!ticket_is_last(&tail.tickets[xg], (unsigned)nbx - 1u, flag)) return;
+    for (int col = threadIdx.x * 2; col < 2 * C; col += 512) {  // rows xg, xg + NC, ... : [2][C] floats each, a lane sums two columns
+        const float* src = part + (int64_t)xg * 2 * C + col;
+        const int64_t rs = (int64_t)NC * 2 * C;  // NC rows on
+        double a0 = 0.0, a1 = 0.0;
+        int j = 0;
+        for (; j + 15 < nbx; j += 16) {  // sixteen loads in flight
+            float x[16], y[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) ld_wt2(src + (int64_t)(j + u) * rs, x[u], y[u]);
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                a0 += (double)x[u];
+                a1 += (double)y[u];
+            }
+        }
+        for (; j < nbx; ++j) {
+            float x, y;
+            ld_wt2(src + (int64_t)j * rs, x, y);
+            a0 += (double)x;
+            a1 += (double)y;
+        }
+        st_wt(&tail.xrows[(int64_t)xg * 2 * C + col], a0);
+        st_wt(&tail.xrows[(int64_t)xg * 2 * C + col + 1], a1);
+    }
+    if (!ticket_is_last(&tail.tickets[32], (unsigned)NC - 1u, flag)) return;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        double sa = 0.0, sb = 0.0;
+        for (int x0 = 0; x0 < NC; x0 += 8) {
+            double v0[8], v1[8];
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                v0[x] = ld_wt(&tail.xrows[((int64_t)(x0 + x) * 2 + 0) * C + c]);
+                v1[x] = ld_wt(&tail.xrows[((int64_t)(x0 + x) * 2 + 1) * C + c]);
+            }
+#pragma unroll
+            for (int x = 0; x < 8; ++x) {
+                sa += v0[x];
+                sb += v1[x];
+            }
+        }
+        if (tail.out0) tail.out0[c] = (float)sa;
+        if (tail.out1) tail.out1[c] = (float)sb;
+        if (tail.bn.coef) bn_coef_write(tail.bn, C, c, (float)sa, (float)sb);
     }
 }
 
@@ -145,18 +245,6 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, i
 // write-back + invalidate on this 8-XCD part and every one of up to 1024 workgroups pays it (17.6 -> 148 us per reduce launch);
 // profiles/r04_bn_tail_ticket_ab.txt, code in git.)
 // 32 channels x 32 row slices per block, 4 independent accumulator pairs per thread (loads in flight)
-// coefficients of the BN backward apply pass, from the finished sums (one set per channel):
-//   z = x*a0 + a1 ;  draw = dy*act'(z)*c0 - x*c1 - c2
-struct BnCoefArgs {
-    const float* gamma;
-    const float* beta;
-    const float* mean;
-    const float* inv;
-    float inv_count;
-    float* coef;  // [5][C] or nullptr
-    GammaBeta2 g2;
-};
-
 __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __restrict__ part, int blocks, int C, float* __restrict__ out0, float* __restrict__ out1,
                                                                  BnCoefArgs bn) {
     __shared__ double red[2][32][33];
@@ -220,6 +308,9 @@ __global__ __launch_bounds__(1024) void chan_reduce_final_kernel(const float* __
     }
 }
 
+// option bn_tail = 0: the final pass as its own launch (the "before" of profiles/r05_bn_tail_ab.txt)
+static bool bn_tail_on() { return ymi_opt(OPT_BN_TAIL) != 0; }
+
 static int pow2_ge(int v) {
     int p = 1;
     while (p < v) p <<= 1;
@@ -238,7 +329,7 @@ static int reduce_blocks(int64_t P, int C) {
     if (ppb < 16) ppb = 16;
     if (ppb > 64) ppb = 64;
     int64_t b = (P + ppb - 1) / ppb;
-    static const int rcap = getenv("YMI_RED_CAP") ? atoi(getenv("YMI_RED_CAP")) : 512;
+    const int rcap = ymi_opt(OPT_RED_CAP);
     if (b > rcap) b = rcap;
     if (b < 1) b = 1;
     return (int)((b + 7) / 8 * 8);  // the same number of workgroups on every XCD (chan_reduce_kernel walks XCD-owned pixel ranges)
@@ -247,16 +338,17 @@ static int reduce_blocks(int64_t P, int C) {
 template <int FN>
 static int launch_chan_reduce(const ymi_tensor* a, const ymi_tensor* b, const float* gamma, const float* beta, const float* mean,
                               const float* inv, int act, float* part, int* blocks_out, hipStream_t stream, const char* what,
-                              GammaBeta2 g2 = GammaBeta2{nullptr, nullptr, 0}) {
+                              GammaBeta2 g2 = GammaBeta2{nullptr, nullptr, 0}, ReduceTail tail = ReduceTail{}) {
     const int64_t P = ymi_pixels(a);
     const int C = (int)a->c;
     YMI_CHECK_ARG(C % 4 == 0 && a->ld % 4 == 0 && (!b || (b->ld % 4 == 0)), "%s: channels must be a multiple of 4", what);
     const int TG = pow2_ge(C / 4) > 256 ? 256 : pow2_ge(C / 4);
     const int crows = (C + 1023) / 1024;
     const int blocks = reduce_blocks(P, C);
+    YMI_CHECK_ARG(!tail.tickets || crows == 1, "%s: the in-kernel final pass covers at most 1024 channels", what);
     const size_t lds = (size_t)256 * 8 * sizeof(float);
     RV ra{a->data, a->ld}, rb{b ? b->data : nullptr, b ? b->ld : 0};
-#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, ymi_xcd_span_arg(P), C, TG, gamma, beta, mean, inv, part, g2)
+#define YMI_CR(T, A) hipLaunchKernelGGL((chan_reduce_kernel<T, FN, A>), dim3(blocks, crows), dim3(256), lds, stream, ra, rb, P, ymi_xcd_span_arg(P), C, TG, gamma, beta, mean, inv, part, g2, tail)
 #define YMI_CR_T(T)                                                      \
     do {                                                                 \
         if (FN != 1 || act == YMI_ACT_NONE) YMI_CR(T, YMI_ACT_NONE);     \
@@ -493,16 +585,27 @@ static int bn_act_bwd_impl(const ymi_tensor* dout, const ymi_tensor* raw, const 
     const int64_t P = ymi_pixels(dout);
     const int C = (int)dout->c;
     const int rblocks = reduce_blocks(P, C);
-    const size_t need = ((size_t)rblocks * 2 * C + 5 * (size_t)C) * sizeof(float);
+    const size_t need = ((size_t)rblocks * 2 * C + 6 * (size_t)C) * sizeof(float) + 64 * (size_t)C * sizeof(double);
     if (workspace_bytes < need) {
         ymi_set_error("bn_act_bwd: workspace %zu < %zu", workspace_bytes, need);
         return YMI_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
     int blocks = 0;
+    float* coef = (float*)workspace + (size_t)rblocks * 2 * C;
+    double* xrows = reinterpret_cast<double*>(coef + 6 * (size_t)C);  // (8-byte aligned: the workspace is, and every term is a multiple of 8 bytes)
+    if (bn_tail_on() && C <= 1024) {
+        // dbeta = sum dz, dgamma = sum dz*xhat and the apply pass's coefficients from the reduce kernel's last workgroups
+        unsigned* tickets = ymi_ticket_slot();
+        YMI_CHECK_ARG(tickets, "bn_act_bwd: ticket counters");
+        const BnCoefArgs bn{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef, g2};
+        int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)", g2,
+                                       ReduceTail{tickets, rblocks % 32 == 0 ? 32 : 8, xrows, dbeta, dgamma, bn});
+        if (rc) return rc;
+        return launch_bn_apply(dout, raw, draw, act, coef, s);
+    }
     int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)", g2);
     if (rc) return rc;
-    float* coef = (float*)workspace + (size_t)blocks * 2 * C;
     // dbeta = sum dz, dgamma = sum dz*xhat, and the apply pass's coefficients
     hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)workspace, blocks, C, dbeta, dgamma,
                        BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef, g2});

@@ -1234,7 +1234,7 @@ extern "C" int ymi_window_attention_fwd(const ymi_tensor* qkv, int64_t wlen, int
     YMI_CHECK_ARG(ymi_tensor_ok(out) && out->c == a.C && ymi_pixels(out) == ymi_pixels(qkv) && out->dtype == qkv->dtype, "window_attention_fwd: out");
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.lse = lse;
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
-    static const int attn_tiled = getenv("YMI_ATTN_TILED") ? atoi(getenv("YMI_ATTN_TILED")) : 0;  // 1: tiled kernels for every window size (tests)
+    const int attn_tiled = ymi_opt(OPT_ATTN_TILED);  // 1: tiled kernels for every window size (tests)
     const size_t lds_tr = (size_t)3 * 64 * (a.hdp + 8) * 2 + (size_t)64 * (64 + 8) * 2;
     if (wlen > 64 || lds > 160 * 1024 || attn_tiled) {
         dim3 tg(grid.x, grid.y, (unsigned)((wlen + 63) / 64));
@@ -1272,7 +1272,7 @@ extern "C" int ymi_window_attention_bwd(const ymi_tensor* qkv, const ymi_tensor*
     a.qkv = SV{qkv->data, qkv->ld}; a.out = SV{out->data, out->ld}; a.dout = SV{dout->data, dout->ld}; a.dqkv = SV{dqkv->data, dqkv->ld};
     a.lse = const_cast<float*>(lse);
     dim3 grid((unsigned)(ymi_pixels(qkv) / wlen), (unsigned)heads);
-    static const int attn_tiled = getenv("YMI_ATTN_TILED") ? atoi(getenv("YMI_ATTN_TILED")) : 0;
+    const int attn_tiled = ymi_opt(OPT_ATTN_TILED);
     const size_t lds_tr = (size_t)4 * 64 * (a.hdp + 8) * 2 + (size_t)2 * 64 * (64 + 8) * 2;
     if (wlen > 64 || lds > 160 * 1024 || attn_tiled) {
         dim3 tg(grid.x, grid.y, (unsigned)((wlen + 63) / 64));

@@ -529,8 +529,8 @@ static WgradPlan wgrad_plan(int64_t mpix, int64_t coutp, int64_t ng, int bm, siz
     // workgroups to aim for (tuning knobs; the in-situ optimum differs from the isolated one: see profiles/r03_wgrad_targets.txt).  Round 4,
     // swept inside the step again (profiles/r04_wgrad_targets_sweep.txt): ONE RESIDENT ROUND - 5 workgroups per CU for the 64-row tile
     // (its launch bounds), 3 for the 128-row tile - is 0.09 ms/step faster than 1024 / 640; a fourth 128-row workgroup per CU costs 0.3 ms
-    static const int target64 = getenv("YMI_WGRAD_BLOCKS") ? atoi(getenv("YMI_WGRAD_BLOCKS")) : 1280;
-    static const int target128 = getenv("YMI_WGRAD_BLOCKS128") ? atoi(getenv("YMI_WGRAD_BLOCKS128")) : 768;
+    const int target64 = ymi_opt(OPT_WGRAD_BLOCKS);
+    const int target128 = ymi_opt(OPT_WGRAD_BLOCKS128);
     const int target = bm == 128 ? target128 : target64;
     int64_t s = (target + tiles - 1) / tiles;
     const int64_t smax = (mpix + 255) / 256;

@@ -48,6 +48,12 @@ typedef struct ymi_tensor {
 
 int ymi_version(void);
 const char* ymi_last_error(void);
+/* Development options: named integers that select the "before" arm of a measured change, a grid size for an in-step sweep or a
+ * forced code path for a test (csrc/common.h: YmiOpt lists them with their defaults; an environment variable YMI_<NAME> present at
+ * process start sets the initial value).  The reference has no counterpart (its knobs are cfg/default.yaml keys); production code sets
+ * none.  set: YMI_EINVAL for an unknown name; get: -1 for an unknown name. */
+int ymi_set_option(const char* name, int64_t value);
+int64_t ymi_get_option(const char* name);
 
 /* Optional live timing of the MFMA GEMM kernels (HIP events on the launch stream) for bench.py's roofline
  * line.  begin(): pre-create events for `capacity` launches and start recording; end(): synchronise the
@@ -409,6 +415,23 @@ int ymi_swin_mlp_fwd(const ymi_tensor* u, const void* w1_packed, const float* b1
                      const ymi_tensor* residual, const ymi_tensor* pre, const ymi_tensor* post, const ymi_tensor* out, void* stream);
 int ymi_swin_mlp_bwd_data(const ymi_tensor* dout, const void* w2_dgrad_packed, const ymi_tensor* pre, const ymi_tensor* dpre,
                           const void* w1_dgrad_packed, const ymi_tensor* add1, const ymi_tensor* add2, const ymi_tensor* du, void* stream);
+
+/* SwinBlock's second half as one kernel per direction: out = x + fc2(gelu(fc1(LayerNorm(x)))) - swin_block.py:53 with the modules of
+ * swin_block.py:30-35 (norm2, mlp) - for bfloat16 tokens of 256 channels (csrc/swin_mlp.hip; `supported` says whether a shape takes this
+ * path, anything else keeps ymi_layernorm_fwd + ymi_swin_mlp_fwd).  The [T, hidden] activations never reach HBM in the forward except, when
+ * training, the bf16 pre-activations once, in a private register-order layout of ymi_swin_ln_mlp_pre_elems(T, hidden) elements.
+ *   pack    : w1 [hidden][c], w2 [c][hidden] (float32, nn.Linear layouts) -> `packed`, ymi_swin_ln_mlp_pack_elems bfloat16 elements (four images)
+ *   fwd     : u / mean / rstd / pre non-null = training (u: LayerNorm output [T][c], saved for fc1's weight gradient and LayerNorm's backward)
+ *   bwd_data: post = gelu(pre) and dpre = (dout W2) * gelu'(pre), both [T][hidden] row-major for the two weight-gradient GEMMs
+ *             (ymi_conv2d_bwd_weight on (post, dout) and (u, dpre)); du = dpre W1 [T][c], LayerNorm's incoming gradient. */
+int ymi_swin_ln_mlp_supported(int64_t c, int64_t hidden, int32_t dtype);
+int64_t ymi_swin_ln_mlp_pack_elems(int64_t c, int64_t hidden);
+int64_t ymi_swin_ln_mlp_pre_elems(int64_t tokens, int64_t hidden);
+int ymi_swin_ln_mlp_pack(const float* w1, const float* w2, int64_t c, int64_t hidden, void* packed, void* stream);
+int ymi_swin_ln_mlp_fwd(const ymi_tensor* x, const float* gamma, const float* beta, float eps, const void* packed, const float* b1, const float* b2,
+                        int64_t hidden, const ymi_tensor* u, float* mean, float* rstd, void* pre, const ymi_tensor* out, void* stream);
+int ymi_swin_ln_mlp_bwd_data(const ymi_tensor* dout, const void* packed, const void* pre, int64_t hidden, const ymi_tensor* post, const ymi_tensor* dpre,
+                             const ymi_tensor* du, void* stream);
 
 #ifdef __cplusplus
 }
