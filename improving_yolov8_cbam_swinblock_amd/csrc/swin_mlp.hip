@@ -5,9 +5,9 @@
 // 87 + 54 us forward and 107 + 54 us of data gradients per block against 18 us bounds (profiles/r04_per_launch_bounds.txt).  Here the
 // hidden activations of a token never leave the registers of the wave that owns the token:
 //
-//  * a workgroup = 128 tokens, a wave = 32 tokens (256 threads, two workgroups per CU).  Waves split ROWS only, so nothing but the weights
-//    is shared: W1 / W2 stream through a two-stage LDS ring in chunks of 32 hidden units (16 KB + 16 KB per chunk, filled by LDS-DMA),
-//    one barrier per chunk.
+//  * a workgroup = 256 tokens, a wave = 32 tokens (512 threads, one workgroup per CU).  Waves split ROWS only, so nothing but the weights
+//    is shared: W1 / W2 stream through a three-stage LDS ring in chunks of 32 hidden units (16 KB + 16 KB per chunk, filled by LDS-DMA);
+//    the two halves of the workgroup run one phase apart (matrix phase beside vector phase on every SIMD: see the schedule note below).
 //  * LayerNorm-2 is the prologue: a lane holds half a token row (16 x 16 bytes), the statistics need one cross-half exchange, and the
 //    normalised row IS the B operand of fc1 (v_mfma_f32_32x32x16_bf16, operands swapped: weights are A, tokens are B, so the 32 x 32
 //    result holds a token per lane and 16 hidden units in its registers).
@@ -23,16 +23,27 @@
 //
 // Arithmetic and rounding points are those of the unfused path (u, pre, post, out stored / consumed as bf16; f32 accumulation), so the
 // bf16 parity bounds of tests/test_gpu_bf16_matched.py are unchanged.  bf16, C = 256, hidden a multiple of 32; other shapes keep the unfused path.
+#include <type_traits>
+
 #include "common.h"
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N-1>{})
+template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 constexpr int MLP_C = 256;         // channels
-constexpr int MLP_BM = 128;        // tokens per workgroup (4 waves x 32)
+constexpr int MLP_BM = 256;        // tokens per workgroup (8 waves x 32)
 constexpr int MLP_HC = 32;         // hidden units per chunk
-constexpr int MLP_STAGE = 32768;   // bytes per ring stage: [32][512] + [256][64]
+constexpr int MLP_STAGE = 32768;   // bytes per ring stage: two 16 KB fragment-major images
+constexpr int MLP_LDS_TILE = 8 * 16384;  // the ring (3 stages) lives in the first 96 KB of the 128 KB the output staging needs
 
 // position p (0..31) of a chunk's permuted hidden order -> hidden unit of the chunk (see the header)
 __host__ __device__ __forceinline__ int mlp_unit_of_pos(int p) {
@@ -41,24 +52,32 @@ __host__ __device__ __forceinline__ int mlp_unit_of_pos(int p) {
 }
 
 // ---- weight operands ---------------------------------------------------------------------------------------------------------------
-// w1 [hidden][C], w2 [C][hidden] (float32, the nn.Linear layouts) -> four bf16 images of hidden * C elements each:
-//   [0] w1p  [hidden][C]            fc1 forward:   A rows = hidden units, k = channel
-//   [1] w2q  [hidden/32][C][32]     fc2 forward:   A rows = channels, k = the chunk's hidden units in permuted order
-//   [2] w2t  [hidden][C]            d_post = d_out W2:  A rows = hidden units, k = channel  (w2 transposed)
-//   [3] w1tq [hidden/32][C][32]     d_u = d_pre W1:     A rows = channels, k = permuted hidden units   (w1 transposed, chunked)
+// w1 [hidden][C], w2 [C][hidden] (float32, the nn.Linear layouts) -> four bf16 images of hidden * C elements each, all FRAGMENT-MAJOR: a
+// chunk of 32 hidden units is 16 KB laid out as the MFMA A fragments the kernels read - [k-step or tile][lane 0..63][8 elements] - so the
+// global image, the LDS image and the lane order coincide: LDS-DMA copies it linearly, a wave's ds_read_b128 of one fragment is 1 KB
+// contiguous (conflict-free, no swizzle), and every LDS address is one per-lane base plus an immediate.
+//   [0] w1f  rows form  [hidden/32][16 k-steps][64 lanes][8]:  A[row = lane & 31 (hidden unit)][k = 16 s + 8 (lane >> 5) + j (channel)] = w1
+//   [1] w2f  cols form  [hidden/32][8 tiles][2 steps][64][8]:  A[row = 32 ct + (lane & 31) (channel)][k = position 16 s + 8 (lane >> 5) + j] = w2,
+//                                                              position p <-> hidden unit mlp_unit_of_pos(p) of the chunk
+//   [2] w2tf rows form of w2 transposed (d_post = d_out W2):   A[hidden unit][channel] = w2[channel][hidden unit]
+//   [3] w1tf cols form of w1 transposed (d_u = d_pre W1):      A[channel][position] = w1[hidden unit of the position][channel]
 __global__ __launch_bounds__(256) void swin_mlp_pack_kernel(const float* __restrict__ w1, const float* __restrict__ w2, int C, int hidden, bf16_t* __restrict__ dst) {
     const int64_t n = (int64_t)C * hidden;
     for (int64_t i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        // plain images: i = hid * C + c
-        const int hid = (int)(i / C), c = (int)(i % C);
-        dst[i] = (bf16_t)w1[i];
-        dst[2 * n + i] = (bf16_t)w2[(int64_t)c * hidden + hid];
-        // chunked images: i = (jc * C + cc) * 32 + p
-        const int p = (int)(i & 31);
-        const int cc = (int)((i >> 5) % C), jc = (int)((i >> 5) / C);
-        const int hu = jc * 32 + mlp_unit_of_pos(p);
-        dst[n + i] = (bf16_t)w2[(int64_t)cc * hidden + hu];
-        dst[3 * n + i] = (bf16_t)w1[(int64_t)hu * C + cc];
+        const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+        const int64_t blk = i >> 9;  // 512-element fragment blocks
+        {   // rows form: blk = jc * 16 + s
+            const int s = (int)(blk & 15), jc = (int)(blk >> 4);
+            const int hu = jc * 32 + (lane & 31), c = 16 * s + 8 * (lane >> 5) + j;
+            dst[i] = (bf16_t)w1[(int64_t)hu * C + c];
+            dst[2 * n + i] = (bf16_t)w2[(int64_t)c * hidden + hu];
+        }
+        {   // cols form: blk = (jc * 8 + ct) * 2 + s
+            const int s = (int)(blk & 1), ct = (int)((blk >> 1) & 7), jc = (int)(blk >> 4);
+            const int c = 32 * ct + (lane & 31), hu = jc * 32 + mlp_unit_of_pos(16 * s + 8 * (lane >> 5) + j);
+            dst[n + i] = (bf16_t)w2[(int64_t)c * hidden + hu];
+            dst[3 * n + i] = (bf16_t)w1[(int64_t)hu * C + c];
+        }
     }
 }
 
@@ -93,6 +112,11 @@ __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast
 // gelu(x) = max(x, 0) - |x| * (0.5 * (1 - erf(|x| / sqrt 2))), the complementary term by Abramowitz-Stegun 7.1.26 (common.h: erf_as; the
 // same six-term form, with the halving folded into the coefficients): 15 issue slots + two transcendentals per element
 __device__ __forceinline__ float gelu_fast(float x, float* half_erfc = nullptr, float* e_out = nullptr) {
+#if YMI_MLP_ABL == 1
+    if (half_erfc) *half_erfc = 0.25f;
+    if (e_out) *e_out = 0.5f;
+    return x;
+#endif
     const float ax = fabsf(x);
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
     const float e = __builtin_amdgcn_exp2f(ax * ax * (-0.5f * 1.44269504088896340736f));
@@ -104,24 +128,94 @@ __device__ __forceinline__ float gelu_fast(float x, float* half_erfc = nullptr, 
     const float w = p * t * e;  // 0.5 * erfc(|x| / sqrt 2)
     if (half_erfc) *half_erfc = w;
     if (e_out) *e_out = e;
-    return fmaf(-ax, w, fmaxf(x, 0.0f));
+    return fmaf(-ax, w, fmaf(0.5f, ax, 0.5f * x));  // max(x, 0) = (x + |x|) / 2, exactly
 }
 
-// issue the LDS-DMA pieces of hidden chunk jc into ring stage `stage` (8 per thread): images [32 rows][512 B] (chunk swizzle ^ (row & 15))
-// and [256 rows][64 B] (chunk swizzle ^ ((row >> 2) & 3)); the destination is lane-linear, the swizzle lives in the source address
+// issue the LDS-DMA pieces of hidden chunk jc into ring stage `stage` (4 per thread): two 16 KB fragment-major images, copied linearly
 __device__ __forceinline__ void mlp_issue(const bf16_t* rows_img, const bf16_t* cols_img, int jc, char* stage, int tid, int wave) {
-    const bf16_t* a = rows_img + (size_t)jc * 32 * MLP_C;
-    const bf16_t* b = cols_img + (size_t)jc * MLP_C * 32;
+#if YMI_MLP_ABL == 4
+    return;
+#endif
+    const bf16_t* a = rows_img + (size_t)jc * 32 * MLP_C + tid * 8;
+    const bf16_t* b = cols_img + (size_t)jc * 32 * MLP_C + tid * 8;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = i * 256 + tid, row = q >> 5, slot = q & 31, kc = slot ^ (row & 15);
-        __builtin_amdgcn_global_load_lds((gptr_t)(a + row * MLP_C + kc * 8), (lptr_t)(stage + (i * 256 + wave * 64) * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(a + i * 4096), (lptr_t)(stage + (i * 512 + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = i * 256 + tid, row = q >> 2, slot = q & 3, kc = slot ^ ((row >> 2) & 3);
-        __builtin_amdgcn_global_load_lds((gptr_t)(b + row * 32 + kc * 8), (lptr_t)(stage + 16384 + (i * 256 + wave * 64) * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds((gptr_t)(b + i * 4096), (lptr_t)(stage + 16384 + (i * 512 + wave * 64) * 16), 16, 0, 0);
+}
+
+// The two products of a chunk with the fragment reads kept AHEAD of the MFMAs.  hipcc places an LDS read right before its use, waits with
+// lgkmcnt(0) and - at 250 live registers - recycles ONE fragment buffer: an exposed LDS round trip (~130 cycles) per 32-cycle MFMA.  So the
+// reads and their counted waits are written out (as igemm.hip's K step): four fragment buffers rotate, three reads stay in flight behind
+// every MFMA.  (Other LDS operations the compiler interleaves only make a counted wait stricter: LDS operations return in order.)
+// diagnostic builds (-DYMI_MLP_ABL=n, results wrong by design; tools/probes/r5_mlp_ablate.sh): 1 no GELU arithmetic, 2 no MFMAs, 3 no fragment reads,
+// 4 no weight copies, 5 no pre-activation stores
+#ifndef YMI_MLP_ABL
+#define YMI_MLP_ABL 0
+#endif
+#if YMI_MLP_ABL == 3
+#define MLP_RD(F, ADDR, OFF) asm volatile("" : "+v"(F) : "v"(ADDR), "n"(OFF))
+#else
+#define MLP_RD(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F) : "v"(ADDR), "n"(OFF))
+#endif
+#if YMI_MLP_ABL == 2
+#define MLP_MFMA(A, B, C) (C)
+#else
+#define MLP_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+#endif
+#define MLP_WAIT(N)                                                    \
+    do {                                                               \
+        __builtin_amdgcn_sched_barrier(0);                             \
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");     \
+    } while (0)
+__device__ __forceinline__ uint32_t lds_u32(const void* p) { return (uint32_t)(uintptr_t)(lptr_t)p; }
+// d += A(rows image: 16 k-steps of 1 KB from `addr`) . b[0..15]
+__device__ __forceinline__ void mlp_rows_product(uint32_t addr, const bf16x8 (&b)[16], f32x16& d) {
+    bf16x8 f[4] = {};
+    MLP_RD(f[0], addr, 0);
+    MLP_RD(f[1], addr, 1024);
+    MLP_RD(f[2], addr, 2048);
+    MLP_RD(f[3], addr, 3072);
+#if YMI_MLP_ABL == 10
+    f32x16 d2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d2[r] = 0.f;
+#endif
+    static_for<0, 16>([&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        const uint32_t ad = addr;  // (an odr-use outside the asm operand: clang does not capture a variable it only sees there)
+        MLP_WAIT((15 - s) < 3 ? (15 - s) : 3);
+        asm volatile("" : "+v"(f[s & 3]));
+#if YMI_MLP_ABL == 10
+        if constexpr (s & 1) d2 = MLP_MFMA(f[s & 3], b[s], d2);
+        else d = MLP_MFMA(f[s & 3], b[s], d);
+#else
+        d = MLP_MFMA(f[s & 3], b[s], d);
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s + 4 < 16) MLP_RD(f[s & 3], ad, (s + 4) * 1024);
+    });
+#if YMI_MLP_ABL == 10
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[r] += d2[r];
+#endif
+}
+// acc[ct] += A(cols image: 8 tiles x 2 steps of 1 KB from `addr`) . hv[0..1]
+__device__ __forceinline__ void mlp_cols_product(uint32_t addr, const bf16x8 (&hv)[2], f32x16 (&acc)[8]) {
+    bf16x8 f[4] = {};
+    MLP_RD(f[0], addr, 0);
+    MLP_RD(f[1], addr, 1024);
+    MLP_RD(f[2], addr, 2048);
+    MLP_RD(f[3], addr, 3072);
+    static_for<0, 16>([&](auto ic) {
+        constexpr int i = decltype(ic)::value;  // i = 2 ct + s
+        const uint32_t ad = addr;
+        MLP_WAIT((15 - i) < 3 ? (15 - i) : 3);
+        asm volatile("" : "+v"(f[i & 3]));
+        acc[i >> 1] = MLP_MFMA(f[i & 3], hv[i & 1], acc[i >> 1]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (i + 4 < 16) MLP_RD(f[i & 3], ad, (i + 4) * 1024);
+    });
 }
 
 // the output tile of a wave ([32 tokens][256 channels] in the 32x32 accumulator layout) -> `dst` rows as whole 512-byte lines, through the
@@ -162,21 +256,54 @@ __device__ __forceinline__ void mlp_store_tile(f32x16 (&acc)[8], const float* bi
     }
 }
 
-template <bool TRAIN>
-__global__ __launch_bounds__(256, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][32 KB] | b1 [hidden] floats
+// Schedule (both kernels).  A workgroup is 8 waves = 256 tokens, one workgroup per CU; waves w and w + 4 share a SIMD.  A wave's chunk
+// is a MATRIX phase (fc2 of the previous chunk + fc1 of this one: 32 MFMAs, fragment reads) followed by a VECTOR phase (bias / GELU /
+// roundings / stores: ~270 VALU instructions), and the two halves of the workgroup (waves 0-3, waves 4-7) run ONE PHASE APART, every
+// phase ending at a workgroup barrier: each SIMD always holds one wave in its matrix phase beside one in its vector phase - the
+// arrangement MI355X_MICROARCH.md "Two waves per SIMD" describes - instead of two waves that drift into the same phase (the first form
+// of this kernel, two independent 4-wave workgroups per CU, measured 24 % MFMA-busy with 37 % of the wave cycles issue-stalled:
+// profiles/r05_swin_mlp_fused.txt).  Global phase t: half 0 runs matrix phases at even t, half 1 at odd t.  Weight chunk c (32 KB) is
+// copied into ring stage c % 3 at the start of phase 2c - 2 (its previous tenant, chunk c - 3, was last read in phase 2c - 3), every
+// wave retires its pieces before the barrier that ends phase 2c - 1, and the first read is in phase 2c.
+__device__ __forceinline__ void mlp_barrier() { asm volatile("s_barrier" ::: "memory"); }
+#if YMI_MLP_ABL == 11
+// diagnostic build: s_memtime stamps of workgroup 100, waves 0 and 4, chunks 8..11, into the (otherwise unused) `mean` array of an evaluation-mode call:
+// [wave half][chunk - 8][point 0..5] = matrix phase start | after the fc2 product | after the fc1 product | past the barrier | vector work done | past the barrier
+#define MLP_STAMP(P)                                                                                                              \
+    do {                                                                                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+        asm volatile("" : "+v"(hv[0]), "+v"(hv[1]));                                                                              \
+        if (!TRAIN && a.mean && blockIdx.x == 100 && (wave & 3) == 0 && lane == 0 && jc >= 8 && jc < 12)                         \
+            reinterpret_cast<unsigned long long*>(a.mean)[(half * 4 + (jc - 8)) * 6 + (P)] = __builtin_amdgcn_s_memtime();           \
+        __builtin_amdgcn_sched_barrier(0);                                                                                        \
+    } while (0)
+#else
+#define MLP_STAMP(P) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
+    const bool TRAIN = a.u != nullptr;  // (kernel argument: uniform) save u, the LayerNorm statistics and the pre-activations
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][32 KB] (the output staging image afterwards: 8 x 16 KB) | b1 [hidden] floats
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#if YMI_MLP_ABL == 8
+    const int half = wave & 1;
+#elif YMI_MLP_ABL == 9
+    const int half = (wave >> 1) & 1;
+#else
+    const int half = wave >> 2;
+#endif
     const int px = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * MLP_BM + wave * 32;
     const int row = row0 + px;
     const bool rok = row < a.T;
     const int rowc = rok ? row : a.T - 1;
-    float* b1s = reinterpret_cast<float*>(smem + 2 * MLP_STAGE);
+    float* b1s = reinterpret_cast<float*>(smem + MLP_LDS_TILE);
     const int nch = a.hidden / MLP_HC;
 
     mlp_issue(a.w1p, a.w2q, 0, smem, tid, wave);
-    for (int i = tid; i < a.hidden; i += 256) b1s[i] = a.b1[i];
+    if (nch > 1) mlp_issue(a.w1p, a.w2q, 1, smem + MLP_STAGE, tid, wave);
+    for (int i = tid; i < a.hidden; i += 512) b1s[i] = a.b1[i];
 
     // ---- LayerNorm-2 (swin_block.py:53 norm2): lane (px, h) holds channels 16 s + 8 h + 0..7 of token row0 + px, s = 0..15 ----------
     bf16x8 uf[16];
@@ -227,58 +354,75 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
-    const uint32_t x1 = (uint32_t)(16 * (h ^ (px & 15)));                      // fc1 image: chunk (2 s + h) ^ (row & 15), row = px
-    const uint32_t k0 = (uint32_t)(16 * (h ^ ((px >> 2) & 3))), k1 = k0 ^ 32u;  // fc2 image: chunk (2 s + h) ^ ((row >> 2) & 3), row = 32 ct + px
-    bf16_t* prew = TRAIN ? a.pre + ((((size_t)blockIdx.x * nch) * 4 + wave) * 4 * 64 + lane) * 4 : nullptr;
+    bf16_t* prew = TRAIN ? a.pre + ((((size_t)blockIdx.x * nch) * 8 + wave) * 4 * 64 + lane) * 4 : nullptr;
+    bf16x8 hv[2];
+    hv[0] = hv[1] = uf[0];  // (defined values; never used before the first vector phase writes them)
 
-    for (int jc = 0; jc < nch; ++jc) {
-        // chunk jc has landed (this wave's pieces: vmcnt; everybody's: the barrier), and every wave is done with the other stage
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        char* st = smem + (jc & 1) * MLP_STAGE;
-        if (jc + 1 < nch) mlp_issue(a.w1p, a.w2q, jc + 1, smem + ((jc + 1) & 1) * MLP_STAGE, tid, wave);
-        // ---- fc1: d1[hidden unit 8 (r >> 2) + 4 h + (r & 3)][token px] over K = 256 channels
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // chunks 0 and 1, the bias vector
+    mlp_barrier();
+    const uint32_t lds0 = lds_u32(smem) + lane * 16;
+    if (half == 1) mlp_barrier();  // the second half idles one phase
+    // iteration jc = this wave's matrix phase (global phase t = 2 jc + half) and vector phase (t + 1) of chunk jc
+    for (int jc = 0; jc <= nch; ++jc) {
+        // ---- matrix phase: fc2 of chunk jc - 1 (acc[ct][channel 32 ct + 8 (r >> 2) + 4 h + (r & 3)][token px] += over its 32 hidden units), then
+        //      fc1 of chunk jc (d1[hidden unit 8 (r >> 2) + 4 h + (r & 3)][token px] over K = 256 channels, starting at the bias)
+        MLP_STAMP(0);
+        if (half == 0 && jc >= 1 && jc + 1 < nch) mlp_issue(a.w1p, a.w2q, jc + 1, smem + ((jc + 1) % 3) * MLP_STAGE, tid, wave);  // (even global phase)
+        if (YMI_MLP_ABL != 6 && YMI_MLP_ABL != 7) __builtin_amdgcn_s_setprio(1);
+        if (jc > 0) mlp_cols_product(lds0 + ((jc - 1) % 3) * MLP_STAGE + 16384, hv, acc);
+        MLP_STAMP(1);
         f32x16 d1;
+        {
+            const int jb = jc < nch ? jc : nch - 1;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) d1[r] = 0.f;
-        const char* w1a = st + px * 512;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + jb * 32 + 8 * q + 4 * h);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1a + ((uint32_t)(32 * s) ^ x1));
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, uf[s], d1, 0, 0, 0);
+                for (int r = 0; r < 4; ++r) d1[4 * q + r] = bb[r];
+            }
         }
-        // ---- bias, bf16 rounding of the pre-activation (saved), exact-erf GELU, bf16 again: the B operand of fc2
+        if (jc < nch) mlp_rows_product(lds0 + (jc % 3) * MLP_STAGE, uf, d1);
+        if (YMI_MLP_ABL != 6 && YMI_MLP_ABL != 7) __builtin_amdgcn_s_setprio(0);
+        MLP_STAMP(2);
+        // (odd global phase for the second half) the pieces issued one phase ago have landed: only the four pre-activation stores are younger
+        if (half == 1) {
+            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        mlp_barrier();
+        MLP_STAMP(3);
+        if (jc == nch) break;
+        // ---- vector phase: bf16 rounding of the pre-activation (saved), exact-erf GELU, bf16 again: the B operand of fc2
+        if (half == 1 && jc + 2 < nch) mlp_issue(a.w1p, a.w2q, jc + 2, smem + ((jc + 2) % 3) * MLP_STAGE, tid, wave);  // (even global phase)
+        if (YMI_MLP_ABL == 7) __builtin_amdgcn_s_setprio(1);
         uint32_t hf[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + jc * 32 + 8 * q + 4 * h);
-            const uint32_t p01 = pack_bf16x2(d1[4 * q + 0] + bb[0], d1[4 * q + 1] + bb[1]);
-            const uint32_t p23 = pack_bf16x2(d1[4 * q + 2] + bb[2], d1[4 * q + 3] + bb[3]);
-            if (TRAIN) {
+            const uint32_t p01 = pack_bf16x2(d1[4 * q + 0], d1[4 * q + 1]);
+            const uint32_t p23 = pack_bf16x2(d1[4 * q + 2], d1[4 * q + 3]);
+            if (TRAIN && YMI_MLP_ABL != 5) {
                 u32x2 pv;
                 pv[0] = p01;
                 pv[1] = p23;
-                *reinterpret_cast<u32x2*>(prew + ((size_t)jc * 4 * 4 + q) * 64 * 4) = pv;
+                *reinterpret_cast<u32x2*>(prew + ((size_t)jc * 8 * 4 + q) * 64 * 4) = pv;
             }
             hf[2 * q + 0] = pack_bf16x2(gelu_fast(bf16_lo(p01)), gelu_fast(bf16_hi(p01)));
             hf[2 * q + 1] = pack_bf16x2(gelu_fast(bf16_lo(p23)), gelu_fast(bf16_hi(p23)));
         }
-        // ---- fc2: acc[ct][channel 32 ct + 8 (r >> 2) + 4 h + (r & 3)][token px] += over this chunk's 32 hidden units (two 16-deep steps)
-        const char* w2a = st + 16384 + px * 64;
-        bf16x8 hv[2];
-        {
-            u32x4 t0 = {hf[0], hf[1], hf[2], hf[3]}, t1 = {hf[4], hf[5], hf[6], hf[7]};
-            hv[0] = __builtin_bit_cast(bf16x8, t0);
-            hv[1] = __builtin_bit_cast(bf16x8, t1);
+        u32x4 t0 = {hf[0], hf[1], hf[2], hf[3]}, t1 = {hf[4], hf[5], hf[6], hf[7]};
+        hv[0] = __builtin_bit_cast(bf16x8, t0);
+        hv[1] = __builtin_bit_cast(bf16x8, t1);
+        if (YMI_MLP_ABL == 7) __builtin_amdgcn_s_setprio(0);
+        MLP_STAMP(4);
+        if (half == 0) {  // (odd global phase for the first half)
+            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const bf16x8 wa = *reinterpret_cast<const bf16x8*>(w2a + ct * 2048 + k0);
-            const bf16x8 wb = *reinterpret_cast<const bf16x8*>(w2a + ct * 2048 + k1);
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hv[0], acc[ct], 0, 0, 0);
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, hv[1], acc[ct], 0, 0, 0);
-        }
+        mlp_barrier();
+        MLP_STAMP(5);
     }
-    __syncthreads();  // every wave has finished reading the ring: it becomes the output staging image
+    if (half == 0) mlp_barrier();  // the first half waits out the second half's last phase
+    // (the last barrier: every wave has finished reading the ring, which becomes the output staging image)
     mlp_store_tile<true>(acc, a.b2, a.x, a.ldx, a.out, a.ldo, row0, a.T, smem + wave * 16384, lane);
 }
 
@@ -302,18 +446,19 @@ struct MlpBwdArgs {
     int T, hidden;
 };
 
-__global__ __launch_bounds__(256, 2) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][32 KB]
+__global__ __launch_bounds__(512, 2) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][32 KB]; the d_u staging image afterwards (8 x 16 KB)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = wave >> 2;
     const int px = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * MLP_BM + wave * 32;
     const int row = row0 + px;
-    const bool rok = row < a.T;
-    const int rowc = rok ? row : a.T - 1;
+    const int rowc = row < a.T ? row : a.T - 1;
     const int nch = a.hidden / MLP_HC;
 
     mlp_issue(a.w2t, a.w1tq, 0, smem, tid, wave);
+    if (nch > 1) mlp_issue(a.w2t, a.w1tq, 1, smem + MLP_STAGE, tid, wave);
     bf16x8 df[16];
     {
         const bf16_t* xr = a.dout + (int64_t)rowc * a.lddo + 8 * h;
@@ -325,28 +470,45 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
     for (int ct = 0; ct < 8; ++ct)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
-    const uint32_t x1 = (uint32_t)(16 * (h ^ (px & 15)));
-    const uint32_t k0 = (uint32_t)(16 * (h ^ ((px >> 2) & 3))), k1 = k0 ^ 32u;
-    const bf16_t* prer = a.pre + ((((size_t)blockIdx.x * nch) * 4 + wave) * 4 * 64 + lane) * 4;
-    bf16_t* postw = a.post + (int64_t)rowc * a.ldpost + 4 * h;
-    bf16_t* dprew = a.dpre + (int64_t)rowc * a.lddpre + 4 * h;
+    // addresses as a wave-uniform base (scalar registers) + a 32-bit per-lane offset: the kernel has no vector registers to spare for pointers
+    const char* pre_base = reinterpret_cast<const char*>(a.pre + (((size_t)blockIdx.x * nch) * 8 + wave) * 4 * 64 * 4);
+    const uint32_t pre_off = (uint32_t)lane * 8u;
+    // post / d_pre rows: ALWAYS stored (rows beyond T land in the padding the caller provides), so that every wave issues the same number
+    // of vector-memory operations per phase: the counted vmcnt below relies on it.  Both are dense [rows][hidden]: one offset serves both
+    const uint32_t row_off = (uint32_t)(((int64_t)row * a.hidden + 4 * h) * 2);
+    char* post_base = reinterpret_cast<char*>(a.post);
+    char* dpre_base = reinterpret_cast<char*>(a.dpre);
+    bf16x8 hv[2];
+    hv[0] = hv[1] = df[0];
 
-    for (int jc = 0; jc < nch; ++jc) {
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        char* st = smem + (jc & 1) * MLP_STAGE;
-        if (jc + 1 < nch) mlp_issue(a.w2t, a.w1tq, jc + 1, smem + ((jc + 1) & 1) * MLP_STAGE, tid, wave);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    mlp_barrier();
+    const uint32_t lds0 = lds_u32(smem) + lane * 16;
+    if (half == 1) mlp_barrier();
+    for (int jc = 0; jc <= nch; ++jc) {
+        // ---- matrix phase: d_u += d_pre(jc - 1) W1 chunk, then d_post(jc) = d_out W2 chunk; the stored pre-activations of chunk jc are
+        //      requested first (four 8-byte loads per lane, used in the vector phase that follows)
+        if (half == 0 && jc >= 1 && jc + 1 < nch) mlp_issue(a.w2t, a.w1tq, jc + 1, smem + ((jc + 1) % 3) * MLP_STAGE, tid, wave);
         u32x2 pv[4];
+        {
+            const int jl = jc < nch ? jc : nch - 1;  // (always four loads: see the counted wait)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) pv[q] = *reinterpret_cast<const u32x2*>(prer + ((size_t)jc * 4 * 4 + q) * 64 * 4);
+            for (int q = 0; q < 4; ++q) pv[q] = *reinterpret_cast<const u32x2*>(pre_base + ((size_t)jl * 8 * 4 + q) * 64 * 8 + pre_off);
+        }
+        __builtin_amdgcn_s_setprio(1);
+        if (jc > 0) mlp_cols_product(lds0 + ((jc - 1) % 3) * MLP_STAGE + 16384, hv, acc);
         f32x16 d1;
 #pragma unroll
         for (int r = 0; r < 16; ++r) d1[r] = 0.f;
-        const char* w1a = st + px * 512;
-#pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const bf16x8 wf = *reinterpret_cast<const bf16x8*>(w1a + ((uint32_t)(32 * s) ^ x1));
-            d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf, df[s], d1, 0, 0, 0);
-        }
+        if (jc < nch) mlp_rows_product(lds0 + (jc % 3) * MLP_STAGE, df, d1);
+        __builtin_amdgcn_s_setprio(0);
+        // (odd global phase for the second half) the pieces issued one phase ago have landed: younger are only eight stores (its vector phase) and
+        // these four loads; the first half below: four loads (its matrix phase) and eight stores
+        if (half == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        mlp_barrier();
+        if (jc == nch) break;
+        // ---- vector phase: post = gelu(pre), d_pre = bf16(d_post) * gelu'(pre), both stored row-major; d_pre is the B operand of the d_u product
+        if (half == 1 && jc + 2 < nch) mlp_issue(a.w2t, a.w1tq, jc + 2, smem + ((jc + 2) % 3) * MLP_STAGE, tid, wave);
         uint32_t hf[8];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -365,29 +527,18 @@ __global__ __launch_bounds__(256, 2) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
             o[1] = pack_bf16x2(po[2], po[3]);
             d[0] = pack_bf16x2(dp[0], dp[1]);
             d[1] = pack_bf16x2(dp[2], dp[3]);
-            if (rok) {
-                *reinterpret_cast<u32x2*>(postw + jc * 32 + 8 * q) = o;
-                *reinterpret_cast<u32x2*>(dprew + jc * 32 + 8 * q) = d;
-            }
+            *reinterpret_cast<u32x2*>(post_base + (size_t)(jc * 64 + 16 * q) + row_off) = o;
+            *reinterpret_cast<u32x2*>(dpre_base + (size_t)(jc * 64 + 16 * q) + row_off) = d;
             hf[2 * q + 0] = d[0];
             hf[2 * q + 1] = d[1];
         }
-        const char* w2a = st + 16384 + px * 64;
-        bf16x8 hv[2];
-        {
-            u32x4 t0 = {hf[0], hf[1], hf[2], hf[3]}, t1 = {hf[4], hf[5], hf[6], hf[7]};
-            hv[0] = __builtin_bit_cast(bf16x8, t0);
-            hv[1] = __builtin_bit_cast(bf16x8, t1);
-        }
-#pragma unroll
-        for (int ct = 0; ct < 8; ++ct) {
-            const bf16x8 wa = *reinterpret_cast<const bf16x8*>(w2a + ct * 2048 + k0);
-            const bf16x8 wb = *reinterpret_cast<const bf16x8*>(w2a + ct * 2048 + k1);
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa, hv[0], acc[ct], 0, 0, 0);
-            acc[ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wb, hv[1], acc[ct], 0, 0, 0);
-        }
+        u32x4 t0 = {hf[0], hf[1], hf[2], hf[3]}, t1 = {hf[4], hf[5], hf[6], hf[7]};
+        hv[0] = __builtin_bit_cast(bf16x8, t0);
+        hv[1] = __builtin_bit_cast(bf16x8, t1);
+        if (half == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        mlp_barrier();
     }
-    __syncthreads();
+    if (half == 0) mlp_barrier();
     mlp_store_tile<false>(acc, nullptr, nullptr, 0, a.du, a.lddu, row0, a.T, smem + wave * 16384, lane);
 }
 
@@ -431,15 +582,10 @@ extern "C" int ymi_swin_ln_mlp_fwd(const ymi_tensor* x, const float* gamma, cons
     a.mean = mean; a.rstd = rstd; a.pre = (bf16_t*)pre;
     a.out = (bf16_t*)out->data; a.ldo = out->ld;
     a.T = (int)T; a.hidden = (int)hidden;
-    const size_t lds = 2 * MLP_STAGE + (size_t)hidden * sizeof(float);
+    const size_t lds = MLP_LDS_TILE + (size_t)hidden * sizeof(float);
     const dim3 grid((unsigned)((T + MLP_BM - 1) / MLP_BM));
-    if (train) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(swin_mlp_fwd_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(swin_mlp_fwd_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, a);
-    }
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(swin_mlp_fwd_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
     YMI_CHECK_LAUNCH("swin_ln_mlp_fwd");
     return YMI_OK;
 }
@@ -455,7 +601,8 @@ extern "C" int ymi_swin_ln_mlp_bwd_data(const ymi_tensor* dout, const void* pack
                       ((((uintptr_t)dout->data) | ((uintptr_t)du->data) | ((uintptr_t)packed) | ((uintptr_t)pre)) & 15) == 0 &&
                       ((((uintptr_t)post->data) | ((uintptr_t)dpre->data)) & 7) == 0,
                   "swin_ln_mlp_bwd_data: alignment");
-    YMI_CHECK_ARG(T < (1ll << 31) && T * post->ld < (1ll << 31), "swin_ln_mlp_bwd_data: too large");
+    YMI_CHECK_ARG(T < (1ll << 31) && (T + MLP_BM) * post->ld < (1ll << 31), "swin_ln_mlp_bwd_data: too large");
+    YMI_CHECK_ARG(post->ld == hidden && dpre->ld == hidden, "swin_ln_mlp_bwd_data: post / dpre are dense [T][hidden] views of buffers of ymi_swin_ln_mlp_pre_elems elements");
     const int64_t n = (int64_t)MLP_C * hidden;
     MlpBwdArgs a{};
     a.dout = (const bf16_t*)dout->data; a.lddo = dout->ld;
@@ -465,9 +612,9 @@ extern "C" int ymi_swin_ln_mlp_bwd_data(const ymi_tensor* dout, const void* pack
     a.dpre = (bf16_t*)dpre->data; a.lddpre = dpre->ld;
     a.du = (bf16_t*)du->data; a.lddu = du->ld;
     a.T = (int)T; a.hidden = (int)hidden;
-    const size_t lds = 2 * MLP_STAGE;
+    const size_t lds = MLP_LDS_TILE;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(swin_mlp_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(swin_mlp_bwd_kernel, dim3((unsigned)((T + MLP_BM - 1) / MLP_BM)), dim3(256), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(swin_mlp_bwd_kernel, dim3((unsigned)((T + MLP_BM - 1) / MLP_BM)), dim3(512), lds, (hipStream_t)stream, a);
     YMI_CHECK_LAUNCH("swin_ln_mlp_bwd_data");
     return YMI_OK;
 }

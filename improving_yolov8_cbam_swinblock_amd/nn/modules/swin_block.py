@@ -50,8 +50,12 @@ class SwinBlock(nn.Module):
         qkv = ops.linear(t1, a.in_proj_weight, a.in_proj_bias)                  # [T, 3C]
         o = ops.window_attention(qkv, ws * ws, a.num_heads)                     # [T, C]
         t2 = ops.linear(o, a.out_proj.weight, a.out_proj.bias, residual=t1)     # skip from normalised tokens
-        if join:
-            ops.mark_join(t2, 2)
-        u = ops.layernorm(t2, self.norm2, 0)
-        t3 = ops.swin_mlp(u, self.mlp[0], self.mlp[2], residual=t2)  # fc1 -> GELU -> fc2 -> + t2, GELU inside the GEMM epilogues
+        if ops.swin_ln_mlp_ok(t2, self.mlp[0]) and self.mlp[0].bias is not None and self.mlp[2].bias is not None:
+            # norm2 -> fc1 -> GELU -> fc2 -> + t2 as one kernel per direction: the [T, 4C] activations never leave the registers (csrc/swin_mlp.hip)
+            t3 = ops.swin_ln_mlp(t2, self.norm2, self.mlp[0], self.mlp[2])
+        else:
+            if join:
+                ops.mark_join(t2, 2)
+            u = ops.layernorm(t2, self.norm2, 0)
+            t3 = ops.swin_mlp(u, self.mlp[0], self.mlp[2], residual=t2)  # fc1 -> GELU -> fc2 -> + t2, GELU inside the GEMM epilogues
         return ops.window_reverse(t3, n, h, w, ws, out)

@@ -1610,6 +1610,86 @@ def swin_mlp(u, fc1, fc2, residual=None):
     return _SwinMlp.apply(u, fc1.weight, fc1.bias, fc2.weight, fc2.bias, residual, join_of(u), join_of(residual) if residual is not None else None)
 
 
+def swin_ln_mlp_ok(x, fc1):
+    """SwinBlock's second half as the fused kernels of csrc/swin_mlp.hip: bfloat16 tokens of 256 channels (fused_swin_mlp: test / A-B hook)."""
+    return (fused_swin_mlp["on"] and x.dim() == 2 and x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.stride(0) % 8 == 0
+            and bool(L().ymi_swin_ln_mlp_supported(x.shape[1], fc1.weight.shape[0], ymi_dtype(x.dtype))))
+
+
+fused_swin_mlp = {"on": True}
+
+
+class _SwinLnMlp(torch.autograd.Function):
+    """out = x + fc2(gelu(fc1(LayerNorm(x)))) on a token matrix - swin_block.py:53 with norm2 and mlp of swin_block.py:30-35 - as ONE forward
+    kernel (the [T, 4C] activations stay in registers; training stores the bf16 pre-activations once, in the kernel's own order) and ONE
+    data-gradient kernel (d_pre = (d_out W2) * gelu'(pre), d_u = d_pre W1; it writes gelu(pre) and d_pre row-major for the two weight-gradient
+    GEMMs), then LayerNorm's backward with the skip's gradient as its addend.  x has no other consumer: no GradJoin."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2):
+        t, c = x.shape
+        hidden = w1.shape[0]
+        dev = x.device
+        lib = L()
+        _note_use(w1, w2)
+        packed = torch.empty(lib.ymi_swin_ln_mlp_pack_elems(c, hidden), dtype=torch.bfloat16, device=dev)
+        check(lib.ymi_swin_ln_mlp_pack(ptr(w1.detach()), ptr(w2.detach()), c, hidden, ptr(packed), stream_ptr()), "swin_ln_mlp_pack")
+        train = any(ctx.needs_input_grad)
+        out = torch.empty((t, c), dtype=x.dtype, device=dev)
+        u = torch.empty((t, c), dtype=x.dtype, device=dev) if train else None
+        stats = torch.empty((2, t), dtype=torch.float32, device=dev) if train else None
+        pre = torch.empty(lib.ymi_swin_ln_mlp_pre_elems(t, hidden), dtype=x.dtype, device=dev) if train else None
+        check(
+            lib.ymi_swin_ln_mlp_fwd(_byref(as_ymi(x)), ptr(gamma), ptr(beta), eps, ptr(packed), ptr(b1), ptr(b2), hidden, _byref(as_ymi(u)) if train else None,
+                                    ptr(stats[0]) if train else None, ptr(stats[1]) if train else None, ptr(pre), _byref(as_ymi(out)), stream_ptr()),
+            "swin_ln_mlp_fwd",
+        )
+        if train:
+            ctx.save_for_backward(x, gamma, w1, w2, u, stats, pre, packed)
+            ctx.biases = (b1, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, gamma, w1, w2, u, stats, pre, packed = ctx.saved_tensors
+        b1, b2 = ctx.biases
+        dtype = x.dtype
+        dev = x.device
+        t, c = x.shape
+        hidden = w1.shape[0]
+        dout = grad_nhwc(dout, dtype)
+        # (the kernel stores whole 256-token tiles: post / dpre are the first t rows of padded buffers)
+        cap = L().ymi_swin_ln_mlp_pre_elems(t, hidden)
+        post = torch.empty(cap, dtype=dtype, device=dev).view(-1, hidden)[:t]
+        dpre = torch.empty(cap, dtype=dtype, device=dev).view(-1, hidden)[:t]
+        du = torch.empty((t, c), dtype=dtype, device=dev)
+        check(L().ymi_swin_ln_mlp_bwd_data(_byref(as_ymi(dout)), ptr(packed), ptr(pre), hidden, _byref(as_ymi(post)), _byref(as_ymi(dpre)), _byref(as_ymi(du)),
+                                           stream_ptr()), "swin_ln_mlp_bwd_data")
+        nig = ctx.needs_input_grad  # (x, gamma, beta, eps, w1, b1, w2, b2)
+        dw1 = db1 = dw2 = db2 = None
+        if nig[6] or nig[7]:
+            dw2, db2 = _wgrad_maybe_async(post, dout, c, hidden, 1, 1, True, (w2, b2))
+            dw2, db2 = (dw2.view(w2.shape) if nig[6] else None), (db2 if nig[7] else None)
+        if nig[4] or nig[5]:
+            dw1, db1 = _wgrad_maybe_async(u, dpre, hidden, c, 1, 1, True, (w1, b1))
+            dw1, db1 = (dw1.view(w1.shape) if nig[4] else None), (db1 if nig[5] else None)
+        # LayerNorm's backward on d_u; the skip's gradient (d_out itself) is its addend: dx = LN'(d_u) + d_out
+        dx = torch.empty_like(x)
+        dgb = torch.empty((2, c), dtype=torch.float32, device=dev)
+        wsb = workspace(2048 * 2 * c * 4 + 256, dev, "ln")
+        check(
+            L().ymi_layernorm_bwd_add(_byref(as_ymi(x)), 0, _byref(as_ymi(du)), ptr(gamma), ptr(stats[0]), ptr(stats[1]), _byref(as_ymi(dout)), _byref(as_ymi(dx)),
+                                      ptr(dgb[0]), ptr(dgb[1]), ptr(wsb), wsb.numel(), stream_ptr()),
+            "layernorm_bwd",
+        )
+        return dx, dgb[0], dgb[1], None, dw1, db1, dw2, db2
+
+
+def swin_ln_mlp(x, ln, fc1, fc2):
+    """x + fc2(gelu(fc1(ln(x)))) (swin_block.py:53) through the fused kernels; callers check swin_ln_mlp_ok first."""
+    return _SwinLnMlp.apply(x, ln.weight, ln.bias, float(ln.eps), fc1.weight, fc1.bias, fc2.weight, fc2.bias)
+
+
 class _Act(torch.autograd.Function):
     """elementwise activation on a token matrix (exact-erf GELU of swin_block.py:33)."""
 

@@ -423,7 +423,8 @@ int ymi_swin_mlp_bwd_data(const ymi_tensor* dout, const void* w2_dgrad_packed, c
  *   pack    : w1 [hidden][c], w2 [c][hidden] (float32, nn.Linear layouts) -> `packed`, ymi_swin_ln_mlp_pack_elems bfloat16 elements (four images)
  *   fwd     : u / mean / rstd / pre non-null = training (u: LayerNorm output [T][c], saved for fc1's weight gradient and LayerNorm's backward)
  *   bwd_data: post = gelu(pre) and dpre = (dout W2) * gelu'(pre), both [T][hidden] row-major for the two weight-gradient GEMMs
- *             (ymi_conv2d_bwd_weight on (post, dout) and (u, dpre)); du = dpre W1 [T][c], LayerNorm's incoming gradient. */
+ *             (ymi_conv2d_bwd_weight on (post, dout) and (u, dpre)); du = dpre W1 [T][c], LayerNorm's incoming gradient.  The kernel stores whole
+ *             256-token tiles: post / dpre are dense (ld == hidden) views of the first T rows of buffers of ymi_swin_ln_mlp_pre_elems elements. */
 int ymi_swin_ln_mlp_supported(int64_t c, int64_t hidden, int32_t dtype);
 int64_t ymi_swin_ln_mlp_pack_elems(int64_t c, int64_t hidden);
 int64_t ymi_swin_ln_mlp_pre_elems(int64_t tokens, int64_t hidden);

@@ -9,9 +9,9 @@ pytestmark = pytest.mark.gpu
 
 
 def _decode_pre(pre_priv, tokens, hidden):
-    """private register-order layout [tile][chunk][wave][q][half][lane32][4] -> [tokens, hidden] (csrc/swin_mlp.hip)"""
-    tiles = (tokens + 127) // 128
-    v = pre_priv.view(tiles, hidden // 32, 4, 4, 2, 32, 4).permute(0, 2, 5, 1, 3, 4, 6).reshape(tiles * 128, hidden)
+    """private register-order layout [tile of 256 tokens][chunk][wave][q][half][lane32][4] -> [tokens, hidden] (csrc/swin_mlp.hip)"""
+    tiles = (tokens + 255) // 256
+    v = pre_priv.view(tiles, hidden // 32, 8, 4, 2, 32, 4).permute(0, 2, 5, 1, 3, 4, 6).reshape(tiles * 256, hidden)
     return v[:tokens]
 
 
@@ -66,7 +66,7 @@ def _inputs(t, hidden, seed):
     return x, gamma, beta, 1e-5, w1, b1, w2, b2
 
 
-@pytest.mark.parametrize("t,hidden", [(128, 32), (421, 1024), (640, 64), (56448 // 8, 1024)])
+@pytest.mark.parametrize("t,hidden", [(128, 32), (256, 64), (421, 1024), (640, 64), (56448 // 8, 1024)])
 def test_fused_forward_against_float64(t, hidden):
     args = _inputs(t, hidden, t + hidden)
     out, u, stats, pre, _ = _fused_fwd(*args)
@@ -122,8 +122,10 @@ def test_fused_backward_data_path_against_float64(t, hidden):
     out, u, stats, pre, packed = _fused_fwd(x, gamma, beta, eps, w1, b1, w2, b2)
     g = torch.Generator().manual_seed(t)
     dout = (torch.randn(t, 256, generator=g) * 0.5).to(torch.bfloat16).to(x.device)
-    post = torch.empty((t, hidden), dtype=torch.bfloat16, device=x.device)
-    dpre = torch.empty_like(post)
+    # post / dpre: the first t rows of buffers padded to whole 256-token tiles (the kernel stores every row of a tile)
+    cap = L.lib().ymi_swin_ln_mlp_pre_elems(t, hidden)
+    post = torch.full((cap,), float("nan"), dtype=torch.bfloat16, device=x.device).view(-1, hidden)[:t]
+    dpre = torch.full((cap,), float("nan"), dtype=torch.bfloat16, device=x.device).view(-1, hidden)[:t]
     du = torch.empty_like(x)
     L.check(L.lib().ymi_swin_ln_mlp_bwd_data(ctypes.byref(L.as_ymi(dout)), L.ptr(packed), L.ptr(pre), hidden, ctypes.byref(L.as_ymi(post)), ctypes.byref(L.as_ymi(dpre)),
                                              ctypes.byref(L.as_ymi(du)), L.stream_ptr()), "bwd_data")
