@@ -220,6 +220,9 @@ def main():
     ap.add_argument("--forward-only", action="store_true",
                     help="profiling aid: run ONLY the train-mode forward (north_star's target metric) - warm-up + `steps` graph replays - and print "
                          "its record; under rocprofv3 --kernel-trace --stats this gives the forward's own kernel table")
+    ap.add_argument("--hook", action="append", default=[], metavar="NAME=VALUE",
+                    help="development aid for same-box A/B runs (tools/r5_ab.sh): set a python hook (ops.HOOKS: fused_swin_mlp, detect_pair, detect_multi, "
+                         "first_conv) or a library option (ymi_set_option: bn_tail, ew_cap, ...) before the model is built; the default command sets none")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -232,6 +235,14 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    for kv in args.hook:
+        from improving_yolov8_cbam_swinblock_amd import ops
+
+        name, _, val = kv.partition("=")
+        if name in ops.HOOKS:
+            ops.HOOKS[name] = bool(int(val))
+        else:
+            _lib.set_option(name, int(val))
     ndev = torch.cuda.device_count()
     local_env = int(os.environ.get("LOCAL_RANK", "0"))
     if args.backend == "nccl" and local_env >= ndev:

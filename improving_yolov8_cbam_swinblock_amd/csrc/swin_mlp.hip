@@ -45,18 +45,20 @@ constexpr int MLP_HC = 32;         // hidden units per chunk
 constexpr int MLP_STAGE = 32768;   // bytes per ring stage: two 16 KB fragment-major images
 constexpr int MLP_LDS_TILE = 8 * 16384;  // the ring (3 stages) lives in the first 96 KB of the 128 KB the output staging needs
 
-// position p (0..31) of a chunk's permuted hidden order -> hidden unit of the chunk (see the header)
-__host__ __device__ __forceinline__ int mlp_unit_of_pos(int p) {
-    const int s = p >> 4, h = (p >> 3) & 1, j = p & 7;
-    return 16 * s + 8 * (j >> 2) + 4 * h + (j & 3);
-}
+// Which hidden unit sits where is this file's choice (it fixes the row order of the fc1 weight image): the unit in row rho of a chunk's 32 x 32
+// result tile is mlp_unit_of_row(rho), chosen so that the 16 results a lane holds (rows 8 q + 4 h + r of the MFMA's C/D layout) are 16
+// CONSECUTIVE hidden units, 16 h + 4 q + r: the bias is four 16-byte loads, the saved pre-activations / post / d_pre leave as 16-byte stores,
+// and the second product's k-step s takes from lane half h the units 16 h + 8 s + 0..7 - 16 contiguous bytes of the natural weight row.
+__host__ __device__ __forceinline__ int mlp_unit_of_row(int rho) { return 16 * ((rho >> 2) & 1) + 4 * (rho >> 3) + (rho & 3); }
+// position p (0..31) of the second product's k order (k-step s = p >> 4, lane half h = (p >> 3) & 1, element j = p & 7) -> hidden unit of the chunk
+__host__ __device__ __forceinline__ int mlp_unit_of_pos(int p) { return 16 * ((p >> 3) & 1) + 8 * (p >> 4) + (p & 7); }
 
 // ---- weight operands ---------------------------------------------------------------------------------------------------------------
 // w1 [hidden][C], w2 [C][hidden] (float32, the nn.Linear layouts) -> four bf16 images of hidden * C elements each, all FRAGMENT-MAJOR: a
 // chunk of 32 hidden units is 16 KB laid out as the MFMA A fragments the kernels read - [k-step or tile][lane 0..63][8 elements] - so the
 // global image, the LDS image and the lane order coincide: LDS-DMA copies it linearly, a wave's ds_read_b128 of one fragment is 1 KB
 // contiguous (conflict-free, no swizzle), and every LDS address is one per-lane base plus an immediate.
-//   [0] w1f  rows form  [hidden/32][16 k-steps][64 lanes][8]:  A[row = lane & 31 (hidden unit)][k = 16 s + 8 (lane >> 5) + j (channel)] = w1
+//   [0] w1f  rows form  [hidden/32][16 k-steps][64 lanes][8]:  A[row = lane & 31 (hidden unit mlp_unit_of_row(row))][k = 16 s + 8 (lane >> 5) + j (channel)] = w1
 //   [1] w2f  cols form  [hidden/32][8 tiles][2 steps][64][8]:  A[row = 32 ct + (lane & 31) (channel)][k = position 16 s + 8 (lane >> 5) + j] = w2,
 //                                                              position p <-> hidden unit mlp_unit_of_pos(p) of the chunk
 //   [2] w2tf rows form of w2 transposed (d_post = d_out W2):   A[hidden unit][channel] = w2[channel][hidden unit]
@@ -68,7 +70,7 @@ __global__ __launch_bounds__(256) void swin_mlp_pack_kernel(const float* __restr
         const int64_t blk = i >> 9;  // 512-element fragment blocks
         {   // rows form: blk = jc * 16 + s
             const int s = (int)(blk & 15), jc = (int)(blk >> 4);
-            const int hu = jc * 32 + (lane & 31), c = 16 * s + 8 * (lane >> 5) + j;
+            const int hu = jc * 32 + mlp_unit_of_row(lane & 31), c = 16 * s + 8 * (lane >> 5) + j;
             dst[i] = (bf16_t)w1[(int64_t)hu * C + c];
             dst[2 * n + i] = (bf16_t)w2[(int64_t)c * hidden + hu];
         }
@@ -110,16 +112,18 @@ __device__ __forceinline__ float bf16_lo(uint32_t v) { return __builtin_bit_cast
 __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast(float, v & 0xffff0000u); }
 
 // gelu(x) = max(x, 0) - |x| * (0.5 * (1 - erf(|x| / sqrt 2))), the complementary term by Abramowitz-Stegun 7.1.26 (common.h: erf_as; the
-// same six-term form, with the halving folded into the coefficients): 15 issue slots + two transcendentals per element
+// same six-term form with the halving folded into the coefficients and the argument scalings into the constants): 11 issue slots + two
+// transcendentals per element - the vector phases of these kernels are bound by exactly this count.
 __device__ __forceinline__ float gelu_fast(float x, float* half_erfc = nullptr, float* e_out = nullptr) {
 #if YMI_MLP_ABL == 1
     if (half_erfc) *half_erfc = 0.25f;
     if (e_out) *e_out = 0.5f;
     return x;
 #endif
-    const float ax = fabsf(x);
+    const float ax = fabsf(x);                                                                // (a source modifier, no instruction)
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-    const float e = __builtin_amdgcn_exp2f(ax * ax * (-0.5f * 1.44269504088896340736f));
+    const float s = ax * 0.84932180028801904272f;                                              // sqrt(0.5 log2 e) |x|
+    const float e = __builtin_amdgcn_exp2f(-(s * s));                                          // e^(-x^2 / 2)
     float p = 0.5f * 1.061405429f;
     p = fmaf(p, t, -0.5f * 1.453152027f);
     p = fmaf(p, t, 0.5f * 1.421413741f);
@@ -128,7 +132,9 @@ __device__ __forceinline__ float gelu_fast(float x, float* half_erfc = nullptr, 
     const float w = p * t * e;  // 0.5 * erfc(|x| / sqrt 2)
     if (half_erfc) *half_erfc = w;
     if (e_out) *e_out = e;
-    return fmaf(-ax, w, fmaf(0.5f, ax, 0.5f * x));  // max(x, 0) = (x + |x|) / 2, exactly
+    float relu;
+    asm("v_max_f32 %0, 0, %1" : "=v"(relu) : "v"(x));  // (fmaxf would first canonicalise x with a second v_max)
+    return fmaf(-ax, w, relu);
 }
 
 // issue the LDS-DMA pieces of hidden chunk jc into ring stage `stage` (4 per thread): two 16 KB fragment-major images, copied linearly
@@ -354,7 +360,8 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
 
-    bf16_t* prew = TRAIN ? a.pre + ((((size_t)blockIdx.x * nch) * 8 + wave) * 4 * 64 + lane) * 4 : nullptr;
+    // saved pre-activations, private layout [tile][chunk][wave][g = 0, 1][lane][8]: units 16 h + 8 g + 0..7 of the chunk for token px
+    bf16_t* prew = TRAIN ? a.pre + ((((size_t)blockIdx.x * nch) * 8 + wave) * 2 * 64 + lane) * 8 : nullptr;
     bf16x8 hv[2];
     hv[0] = hv[1] = uf[0];  // (defined values; never used before the first vector phase writes them)
 
@@ -376,7 +383,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
             const int jb = jc < nch ? jc : nch - 1;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + jb * 32 + 8 * q + 4 * h);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(b1s + jb * 32 + 16 * h + 4 * q);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) d1[4 * q + r] = bb[r];
             }
@@ -384,9 +391,9 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
         if (jc < nch) mlp_rows_product(lds0 + (jc % 3) * MLP_STAGE, uf, d1);
         if (YMI_MLP_ABL != 6 && YMI_MLP_ABL != 7) __builtin_amdgcn_s_setprio(0);
         MLP_STAMP(2);
-        // (odd global phase for the second half) the pieces issued one phase ago have landed: only the four pre-activation stores are younger
+        // (odd global phase for the second half) the pieces issued one phase ago have landed: only the two pre-activation stores are younger
         if (half == 1) {
-            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         mlp_barrier();
@@ -395,19 +402,15 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
         // ---- vector phase: bf16 rounding of the pre-activation (saved), exact-erf GELU, bf16 again: the B operand of fc2
         if (half == 1 && jc + 2 < nch) mlp_issue(a.w1p, a.w2q, jc + 2, smem + ((jc + 2) % 3) * MLP_STAGE, tid, wave);  // (even global phase)
         if (YMI_MLP_ABL == 7) __builtin_amdgcn_s_setprio(1);
-        uint32_t hf[8];
+        uint32_t hf[8], pf[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const uint32_t p01 = pack_bf16x2(d1[4 * q + 0], d1[4 * q + 1]);
-            const uint32_t p23 = pack_bf16x2(d1[4 * q + 2], d1[4 * q + 3]);
-            if (TRAIN && YMI_MLP_ABL != 5) {
-                u32x2 pv;
-                pv[0] = p01;
-                pv[1] = p23;
-                *reinterpret_cast<u32x2*>(prew + ((size_t)jc * 8 * 4 + q) * 64 * 4) = pv;
-            }
-            hf[2 * q + 0] = pack_bf16x2(gelu_fast(bf16_lo(p01)), gelu_fast(bf16_hi(p01)));
-            hf[2 * q + 1] = pack_bf16x2(gelu_fast(bf16_lo(p23)), gelu_fast(bf16_hi(p23)));
+        for (int i = 0; i < 8; ++i) {
+            pf[i] = pack_bf16x2(d1[2 * i], d1[2 * i + 1]);
+            hf[i] = pack_bf16x2(gelu_fast(bf16_lo(pf[i])), gelu_fast(bf16_hi(pf[i])));
+        }
+        if (TRAIN && YMI_MLP_ABL != 5) {
+            *reinterpret_cast<u32x4*>(prew + ((size_t)jc * 8 * 2 + 0) * 64 * 8) = u32x4{pf[0], pf[1], pf[2], pf[3]};
+            *reinterpret_cast<u32x4*>(prew + ((size_t)jc * 8 * 2 + 1) * 64 * 8) = u32x4{pf[4], pf[5], pf[6], pf[7]};
         }
         u32x4 t0 = {hf[0], hf[1], hf[2], hf[3]}, t1 = {hf[4], hf[5], hf[6], hf[7]};
         hv[0] = __builtin_bit_cast(bf16x8, t0);
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
         if (YMI_MLP_ABL == 7) __builtin_amdgcn_s_setprio(0);
         MLP_STAMP(4);
         if (half == 0) {  // (odd global phase for the first half)
-            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         mlp_barrier();
@@ -471,11 +474,11 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ct][r] = 0.f;
     // addresses as a wave-uniform base (scalar registers) + a 32-bit per-lane offset: the kernel has no vector registers to spare for pointers
-    const char* pre_base = reinterpret_cast<const char*>(a.pre + (((size_t)blockIdx.x * nch) * 8 + wave) * 4 * 64 * 4);
-    const uint32_t pre_off = (uint32_t)lane * 8u;
+    const char* pre_base = reinterpret_cast<const char*>(a.pre + (((size_t)blockIdx.x * nch) * 8 + wave) * 2 * 64 * 8);
+    const uint32_t pre_off = (uint32_t)lane * 16u;
     // post / d_pre rows: ALWAYS stored (rows beyond T land in the padding the caller provides), so that every wave issues the same number
     // of vector-memory operations per phase: the counted vmcnt below relies on it.  Both are dense [rows][hidden]: one offset serves both
-    const uint32_t row_off = (uint32_t)(((int64_t)row * a.hidden + 4 * h) * 2);
+    const uint32_t row_off = (uint32_t)(((int64_t)row * a.hidden + 16 * h) * 2);
     char* post_base = reinterpret_cast<char*>(a.post);
     char* dpre_base = reinterpret_cast<char*>(a.dpre);
     bf16x8 hv[2];
@@ -487,13 +490,13 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
     if (half == 1) mlp_barrier();
     for (int jc = 0; jc <= nch; ++jc) {
         // ---- matrix phase: d_u += d_pre(jc - 1) W1 chunk, then d_post(jc) = d_out W2 chunk; the stored pre-activations of chunk jc are
-        //      requested first (four 8-byte loads per lane, used in the vector phase that follows)
+        //      requested first (two 16-byte loads per lane, used in the vector phase that follows)
         if (half == 0 && jc >= 1 && jc + 1 < nch) mlp_issue(a.w2t, a.w1tq, jc + 1, smem + ((jc + 1) % 3) * MLP_STAGE, tid, wave);
-        u32x2 pv[4];
+        u32x4 pv[2];
         {
-            const int jl = jc < nch ? jc : nch - 1;  // (always four loads: see the counted wait)
+            const int jl = jc < nch ? jc : nch - 1;  // (always two loads: see the counted wait)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) pv[q] = *reinterpret_cast<const u32x2*>(pre_base + ((size_t)jl * 8 * 4 + q) * 64 * 8 + pre_off);
+            for (int g = 0; g < 2; ++g) pv[g] = *reinterpret_cast<const u32x4*>(pre_base + ((size_t)jl * 8 * 2 + g) * 64 * 16 + pre_off);
         }
         __builtin_amdgcn_s_setprio(1);
         if (jc > 0) mlp_cols_product(lds0 + ((jc - 1) % 3) * MLP_STAGE + 16384, hv, acc);
@@ -502,40 +505,38 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_bwd_kernel(MlpBwdArgs a) {
         for (int r = 0; r < 16; ++r) d1[r] = 0.f;
         if (jc < nch) mlp_rows_product(lds0 + (jc % 3) * MLP_STAGE, df, d1);
         __builtin_amdgcn_s_setprio(0);
-        // (odd global phase for the second half) the pieces issued one phase ago have landed: younger are only eight stores (its vector phase) and
-        // these four loads; the first half below: four loads (its matrix phase) and eight stores
-        if (half == 1) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        // (odd global phase for the second half) the pieces issued one phase ago have landed: younger are only four stores (its vector phase) and
+        // these two loads; the first half below: two loads (its matrix phase) and four stores
+        if (half == 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         mlp_barrier();
         if (jc == nch) break;
         // ---- vector phase: post = gelu(pre), d_pre = bf16(d_post) * gelu'(pre), both stored row-major; d_pre is the B operand of the d_u product
         if (half == 1 && jc + 2 < nch) mlp_issue(a.w2t, a.w1tq, jc + 2, smem + ((jc + 2) % 3) * MLP_STAGE, tid, wave);
-        uint32_t hf[8];
+        uint32_t hf[8], of[8];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            float po[4], dp[4];
+        for (int i = 0; i < 8; ++i) {  // registers 2 i, 2 i + 1: units 16 h + 2 i, + 1
+            float po[2], dp[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float x = (r & 1) ? bf16_hi(pv[q][r >> 1]) : bf16_lo(pv[q][r >> 1]);
+            for (int r = 0; r < 2; ++r) {
+                const float x = r ? bf16_hi(pv[i >> 2][i & 3]) : bf16_lo(pv[i >> 2][i & 3]);
                 float w, e;
                 po[r] = gelu_fast(x, &w, &e);
                 const float phi = x >= 0.f ? 1.0f - w : w;
                 const float grad = fmaf(x * 0.39894228040143267794f, e, phi);
-                dp[r] = to_f32(from_f32<bf16_t>(d1[4 * q + r])) * grad;
+                dp[r] = to_f32(from_f32<bf16_t>(d1[2 * i + r])) * grad;
             }
-            u32x2 o, d;
-            o[0] = pack_bf16x2(po[0], po[1]);
-            o[1] = pack_bf16x2(po[2], po[3]);
-            d[0] = pack_bf16x2(dp[0], dp[1]);
-            d[1] = pack_bf16x2(dp[2], dp[3]);
-            *reinterpret_cast<u32x2*>(post_base + (size_t)(jc * 64 + 16 * q) + row_off) = o;
-            *reinterpret_cast<u32x2*>(dpre_base + (size_t)(jc * 64 + 16 * q) + row_off) = d;
-            hf[2 * q + 0] = d[0];
-            hf[2 * q + 1] = d[1];
+            of[i] = pack_bf16x2(po[0], po[1]);
+            hf[i] = pack_bf16x2(dp[0], dp[1]);
+        }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            *reinterpret_cast<u32x4*>(post_base + (size_t)(jc * 64 + 16 * g) + row_off) = u32x4{of[4 * g], of[4 * g + 1], of[4 * g + 2], of[4 * g + 3]};
+            *reinterpret_cast<u32x4*>(dpre_base + (size_t)(jc * 64 + 16 * g) + row_off) = u32x4{hf[4 * g], hf[4 * g + 1], hf[4 * g + 2], hf[4 * g + 3]};
         }
         u32x4 t0 = {hf[0], hf[1], hf[2], hf[3]}, t1 = {hf[4], hf[5], hf[6], hf[7]};
         hv[0] = __builtin_bit_cast(bf16x8, t0);
         hv[1] = __builtin_bit_cast(bf16x8, t1);
-        if (half == 0) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        if (half == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         mlp_barrier();
     }
     if (half == 0) mlp_barrier();
@@ -599,7 +600,7 @@ extern "C" int ymi_swin_ln_mlp_bwd_data(const ymi_tensor* dout, const void* pack
                   "swin_ln_mlp_bwd_data: shapes");
     YMI_CHECK_ARG(dout->ld % 8 == 0 && du->ld % 8 == 0 && post->ld % 4 == 0 && dpre->ld % 4 == 0 &&
                       ((((uintptr_t)dout->data) | ((uintptr_t)du->data) | ((uintptr_t)packed) | ((uintptr_t)pre)) & 15) == 0 &&
-                      ((((uintptr_t)post->data) | ((uintptr_t)dpre->data)) & 7) == 0,
+                      ((((uintptr_t)post->data) | ((uintptr_t)dpre->data)) & 15) == 0,
                   "swin_ln_mlp_bwd_data: alignment");
     YMI_CHECK_ARG(T < (1ll << 31) && (T + MLP_BM) * post->ld < (1ll << 31), "swin_ln_mlp_bwd_data: too large");
     YMI_CHECK_ARG(post->ld == hidden && dpre->ld == hidden, "swin_ln_mlp_bwd_data: post / dpre are dense [T][hidden] views of buffers of ymi_swin_ln_mlp_pre_elems elements");

@@ -80,7 +80,7 @@ class Detect(nn.Module):
         convolution with c2 + c3 output channels (ops.conv_bn_act_pair).  A static property of the module (the model graph counts Detect as
         ONE consumer of each input when it holds): both are unfused Conv blocks with SiLU and widths in whole 16-byte bf16 chunks."""
         a, b = self.cv2[0][0], self.cv3[0][0]
-        if os.environ.get("YMI_DETECT_PAIR", "1") == "0":  # diagnostic knob: the two branches as separate convolutions (same-box A/B)
+        if not ops.HOOKS["detect_pair"]:  # test / A-B hook: the two branches as separate convolutions
             return False
         return (hasattr(a, "bn") and hasattr(b, "bn") and isinstance(a.act, nn.SiLU) and isinstance(b.act, nn.SiLU)
                 and a.conv.out_channels % 8 == 0 and b.conv.out_channels % 8 == 0 and a.conv.kernel_size == b.conv.kernel_size)

@@ -24,6 +24,16 @@ def L():
     return _lib.lib()
 
 
+# Test / A-B hooks (python side; the library's own are behind _lib.set_option): each is the "before" arm of a measured change.  Production code
+# never touches them; tests flip them in place, bench.py --hook name=0 sets them for a same-box A/B (tools/r5_ab.sh).
+HOOKS = {
+    "fused_swin_mlp": True,  # SwinBlock's second half as the fused kernels of csrc/swin_mlp.hip (False: LayerNorm + two token GEMMs)
+    "detect_pair": True,     # Detect's sibling first convolutions as one (False: separately)
+    "detect_multi": True,    # Detect's levels in lockstep, one multi-problem launch per stage (False: level by level)
+    "first_conv": True,      # layer 0 through the direct kernels of csrc/first_conv.hip (False: the generic path)
+}
+
+
 def compute_dtype(x):
     if torch.is_autocast_enabled("cuda") if hasattr(torch, "is_autocast_enabled") else False:
         dt = torch.get_autocast_dtype("cuda")
@@ -964,7 +974,7 @@ def first_conv_ok(x, conv, residual, slot):
     return (residual is None and slot is None and torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and x.dtype == torch.float32 and x.is_contiguous()
             and x.shape[1] <= 4 and not x.requires_grad and conv.kernel_size == (3, 3) and conv.stride == (2, 2) and conv.in_channels == x.shape[1]
             and conv.out_channels in (16, 32, 48, 64) and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0 and x.data_ptr() % 16 == 0 and compute_dtype(x) == torch.bfloat16
-            and os.environ.get("YMI_FIRST_CONV", "1") != "0")
+            and HOOKS["first_conv"])
 
 
 def first_conv_bn_act(img, weight, bn, act=ACT_SILU):
@@ -1324,7 +1334,7 @@ def detect_train_ok(levels, dtype):
     """the lockstep form needs: at most 4 levels (8 problems a launch), 3x3 / 3x3 / 1x1 stride-1 branches with SiLU Conv blocks, branch
     widths in whole 16-byte chunks and of ONE width class (both halves of a stage ride in one launch, which fixes the row tile the
     shared statistics rows are counted in), BatchNorms with one eps / momentum."""
-    if os.environ.get("YMI_DETECT_MULTI", "1") == "0" or not (1 <= len(levels) <= 4):
+    if not HOOKS["detect_multi"] or not (1 <= len(levels) <= 4):
         return False
     ch = chunk_elems(dtype)
     eps = mom = None
@@ -1611,12 +1621,10 @@ def swin_mlp(u, fc1, fc2, residual=None):
 
 
 def swin_ln_mlp_ok(x, fc1):
-    """SwinBlock's second half as the fused kernels of csrc/swin_mlp.hip: bfloat16 tokens of 256 channels (fused_swin_mlp: test / A-B hook)."""
-    return (fused_swin_mlp["on"] and x.dim() == 2 and x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.stride(0) % 8 == 0
+    """SwinBlock's second half as the fused kernels of csrc/swin_mlp.hip: bfloat16 tokens of 256 channels (HOOKS["fused_swin_mlp"]: test / A-B hook)."""
+    return (HOOKS["fused_swin_mlp"] and x.dim() == 2 and x.is_cuda and x.dtype == torch.bfloat16 and x.stride(1) == 1 and x.stride(0) % 8 == 0
             and bool(L().ymi_swin_ln_mlp_supported(x.shape[1], fc1.weight.shape[0], ymi_dtype(x.dtype))))
 
-
-fused_swin_mlp = {"on": True}
 
 
 class _SwinLnMlp(torch.autograd.Function):

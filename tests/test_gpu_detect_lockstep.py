@@ -3,7 +3,6 @@ stage, ymi_conv2d_fwd_multi / ymi_conv2d_bwd_data_multi) against the level-by-le
 levels) - outputs, every gradient, running statistics, deferred slab sums; and the two multi-problem entry points against their
 one-problem forms on ragged shapes."""
 import ctypes
-import os
 
 import pytest
 import torch
@@ -41,8 +40,8 @@ def _run(m, xs, lockstep, dtype, deferred=False, used=None):
     from improving_yolov8_cbam_swinblock_amd import ops
 
     m.zero_grad(set_to_none=True)
-    prev = os.environ.get("YMI_DETECT_MULTI")
-    os.environ["YMI_DETECT_MULTI"] = "1" if lockstep else "0"
+    prev = ops.HOOKS["detect_multi"]
+    ops.HOOKS["detect_multi"] = bool(lockstep)
     calls = []
     orig = ops.detect_train
     ops.detect_train = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
@@ -56,10 +55,7 @@ def _run(m, xs, lockstep, dtype, deferred=False, used=None):
             loss.backward()
     finally:
         ops.detect_train = orig
-        if prev is None:
-            os.environ.pop("YMI_DETECT_MULTI", None)
-        else:
-            os.environ["YMI_DETECT_MULTI"] = prev
+        ops.HOOKS["detect_multi"] = prev
     torch.cuda.synchronize()
     assert bool(calls) == bool(lockstep), "the lockstep path did not run" if lockstep else "the level-by-level path did not run"
     grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
@@ -130,7 +126,7 @@ def test_a_detect_the_lockstep_form_does_not_cover_falls_back():
     assert not ops.detect_train_ok(levels, torch.bfloat16)
     g = torch.Generator().manual_seed(5)
     xs = [torch.randn(2, c, s, s, generator=g).to(dev()) for c, s in ((32, 8), (64, 4), (128, 2))]
-    os.environ.pop("YMI_DETECT_MULTI", None)
+    assert ops.HOOKS["detect_multi"]
     with torch.autocast("cuda", dtype=torch.bfloat16):
         box, cls = m.forward_split([x.clone().requires_grad_(True) for x in xs])
     assert [tuple(b.shape) for b in box] == [(2, 64, 8, 8), (2, 64, 4, 4), (2, 64, 2, 2)] and all(c.shape[1] == 3 for c in cls)

@@ -28,7 +28,9 @@ def _conv(cin, cout, seed):
 
 
 def _run(m, img, direct, monkeypatch):
-    monkeypatch.setenv("YMI_FIRST_CONV", "1" if direct else "0")
+    from improving_yolov8_cbam_swinblock_amd import ops
+
+    monkeypatch.setitem(ops.HOOKS, "first_conv", bool(direct))
     m.zero_grad(set_to_none=True)
     with torch.autocast("cuda", dtype=torch.bfloat16):
         y = m(img)
@@ -66,7 +68,6 @@ def test_first_conv_direct_vs_matched_oracle(monkeypatch):
     from oracle import quant
     from improving_yolov8_cbam_swinblock_amd.nn.modules import Conv
 
-    monkeypatch.setenv("YMI_FIRST_CONV", "1")
     torch.manual_seed(11)
     o = OM.Conv(3, 32, 3, 2)
     o.bn.eps, o.bn.momentum = 1e-3, 0.03

@@ -9,9 +9,10 @@ pytestmark = pytest.mark.gpu
 
 
 def _decode_pre(pre_priv, tokens, hidden):
-    """private register-order layout [tile of 256 tokens][chunk][wave][q][half][lane32][4] -> [tokens, hidden] (csrc/swin_mlp.hip)"""
+    """private register-order layout [tile of 256 tokens][chunk][wave][g][half][lane32][8]: hidden unit 32 chunk + 16 half + 8 g + e of token
+    256 tile + 32 wave + lane32 -> [tokens, hidden] (csrc/swin_mlp.hip)"""
     tiles = (tokens + 255) // 256
-    v = pre_priv.view(tiles, hidden // 32, 8, 4, 2, 32, 4).permute(0, 2, 5, 1, 3, 4, 6).reshape(tiles * 256, hidden)
+    v = pre_priv.view(tiles, hidden // 32, 8, 2, 2, 32, 8).permute(0, 2, 5, 1, 4, 3, 6).reshape(tiles * 256, hidden)
     return v[:tokens]
 
 
