@@ -75,6 +75,8 @@ _SIGNATURES = {
         _c_i32,
         [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _TP, _vp, _vp, _vp, _sz, _vp],
     ),
+    "ymi_conv2d_bn_silu_fwd_acc_ok": (_c_i32, [_TP, _TP, _TP]),
+    "ymi_conv2d_bn_silu_fwd_acc": (_c_i32, [_TP, _vp, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _vp, _c_f32, _c_f32, _c_i32, _TP, _TP, _TP, _vp, _vp, _vp, _vp]),
     "ymi_bn_act_bwd": (_c_i32, [_TP, _TP, _vp, _vp, _vp, _vp, _c_i32, _TP, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bn_silu_fwd_pair": (
         _c_i32,

@@ -38,6 +38,13 @@ static inline bool ymi_tensor_ok(const ymi_tensor* t) {
     return t && t->data && t->n > 0 && t->h > 0 && t->w > 0 && t->c > 0 && t->ld >= t->c && (t->dtype == YMI_F32 || t->dtype == YMI_BF16);
 }
 static inline int64_t ymi_pixels(const ymi_tensor* t) { return t->n * t->h * t->w; }
+// binary point of the fixed-point BatchNorm statistics (igemm.hip statistics epilogue -> elementwise.hip BnFin): 37 - ceil(log2(count)), in [8, 40]
+static inline int ymi_stat_fixed_point_shift(int64_t count) {
+    int lg = 0;
+    while (((int64_t)1 << lg) < count) ++lg;
+    const int sh = 37 - lg;
+    return sh < 8 ? 8 : sh > 40 ? 40 : sh;
+}
 static inline size_t ymi_esize(int dtype) { return dtype == YMI_BF16 ? 2 : 4; }
 static inline bool ymi_same_shape(const ymi_tensor* a, const ymi_tensor* b) {
     return a->n == b->n && a->h == b->h && a->w == b->w && a->c == b->c;

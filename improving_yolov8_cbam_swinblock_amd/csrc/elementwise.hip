@@ -1,6 +1,8 @@
 // Memory-bound helpers: layout changes, casts, weight packing, BatchNorm finalize / affine+activation.
 // All are grid-stride kernels over 4-element groups (8 B bf16 / 16 B f32 per lane access); tensors
 // whose ld or base is not 4-element aligned take a scalar path.
+#include <math.h>
+
 #include "common.h"
 
 static inline dim3 ew_grid(int64_t work) {
@@ -482,9 +484,25 @@ __global__ void scale_shift_act_kernel(TV x, const float* __restrict__ scale, co
 
 // Fast path: the number of 4-channel groups divides the block size, so a thread keeps ONE channel group for
 // all its pixels and holds scale/shift in registers; 8-byte (bf16) / 16-byte (f32) accesses, coalesced along C.
-template <typename T, int ACT>
+// BatchNorm finalize folded into the affine pass (round 5): `fin.acc` holds the statistics of this layer as fixed-point sums
+// [4 replicas][2][C] (igemm.hip's statistics epilogue).  Every thread derives scale / shift of ITS four channels in the prologue (eight
+// 16-byte loads, all in flight together, double arithmetic as bn_finalize_kernel); workgroup 0 also writes the saved mean / inverse
+// deviation and updates the running statistics (conv.py:66-67; torch_utils.py:468-470 sets eps / momentum).  nullptr: scale / shift arrays.
+struct BnFin {
+    const long long* acc;
+    const float* gamma;
+    const float* beta;
+    float* rmean;
+    float* rvar;
+    float* smean;
+    float* sinv;
+    double count;
+    double inv_scale;  // 2^-shift of the fixed-point sums (common.h: ymi_stat_fixed_point_shift)
+    float momentum, eps;
+};
+template <typename T, int ACT, bool FIN = false>
 __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const float* __restrict__ scale, const float* __restrict__ shift,
-                                                                    TV res, TV o, int groups, int64_t Pall, int64_t span) {
+                                                                    TV res, TV o, int groups, int64_t Pall, int64_t span, BnFin fin = BnFin{}) {
     // pixels of this workgroup's XCD only (common.h, XCD ownership of the pixel axis): the GEMM that wrote `x` and the one that will read
     // `o` give this XCD the same eighth
     const XcdRange xr = xcd_range(Pall, span);
@@ -493,10 +511,53 @@ __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const 
     const int rows_per_block = 256 / groups;
     if ((int)threadIdx.x >= rows_per_block * groups) return;  // group counts that do not divide 256 (192 channels: 48 groups, 5 rows, 16 idle threads); no barriers below
     float sc[4], sh[4];
+    if constexpr (FIN) {
+        const int C = groups * 4;
+        typedef __attribute__((ext_vector_type(2))) long long i64x2;
+        i64x2 q[4][2][2];  // [replica][sum | sum of squares][channel pair]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        sc[r] = scale ? scale[g * 4 + r] : 1.0f;
-        sh[r] = shift ? shift[g * 4 + r] : 0.0f;
+        for (int rep = 0; rep < 4; ++rep)
+#pragma unroll
+            for (int w = 0; w < 2; ++w)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) q[rep][w][h] = *reinterpret_cast<const i64x2*>(fin.acc + (int64_t)(rep * 2 + w) * C + g * 4 + 2 * h);
+        const f32x4 ga = fin.gamma ? *reinterpret_cast<const f32x4*>(fin.gamma + g * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+        const f32x4 be = fin.beta ? *reinterpret_cast<const f32x4*>(fin.beta + g * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        const bool writer = blockIdx.x == 0 && (int)threadIdx.x < groups;  // one thread per channel group of workgroup 0
+        f32x4 rm = {0.f, 0.f, 0.f, 0.f}, rv = {0.f, 0.f, 0.f, 0.f};
+        if (writer && fin.rmean) rm = *reinterpret_cast<const f32x4*>(fin.rmean + g * 4);
+        if (writer && fin.rvar) rv = *reinterpret_cast<const f32x4*>(fin.rvar + g * 4);
+        f32x4 mean4, inv4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long long s1 = (q[0][0][r >> 1][r & 1] + q[1][0][r >> 1][r & 1]) + (q[2][0][r >> 1][r & 1] + q[3][0][r >> 1][r & 1]);
+            const long long s2 = (q[0][1][r >> 1][r & 1] + q[1][1][r >> 1][r & 1]) + (q[2][1][r >> 1][r & 1] + q[3][1][r >> 1][r & 1]);
+            const double mean = (double)s1 * fin.inv_scale / fin.count;
+            double var = (double)s2 * fin.inv_scale / fin.count - mean * mean;
+            if (var < 0.0) var = 0.0;
+            const float inv = (float)(1.0 / sqrt(var + (double)fin.eps));
+            sc[r] = ga[r] * inv;
+            sh[r] = be[r] - (float)mean * sc[r];
+            mean4[r] = (float)mean;
+            inv4[r] = inv;
+            if (writer) {
+                rm[r] = (1.0f - fin.momentum) * rm[r] + fin.momentum * (float)mean;
+                const double unb = fin.count > 1.0 ? var * fin.count / (fin.count - 1.0) : var;
+                rv[r] = (1.0f - fin.momentum) * rv[r] + fin.momentum * (float)unb;
+            }
+        }
+        if (writer) {
+            if (fin.smean) *reinterpret_cast<f32x4*>(fin.smean + g * 4) = mean4;
+            if (fin.sinv) *reinterpret_cast<f32x4*>(fin.sinv + g * 4) = inv4;
+            if (fin.rmean) *reinterpret_cast<f32x4*>(fin.rmean + g * 4) = rm;
+            if (fin.rvar) *reinterpret_cast<f32x4*>(fin.rvar + g * 4) = rv;
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            sc[r] = scale ? scale[g * 4 + r] : 1.0f;
+            sh[r] = shift ? shift[g * 4 + r] : 0.0f;
+        }
     }
     const T* xp = reinterpret_cast<const T*>(x.p);
     const T* rp = reinterpret_cast<const T*>(res.p);
@@ -549,7 +610,7 @@ __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const 
 }
 
 template <typename T>
-static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const float* shift, int act, TV r, const ymi_tensor* out, hipStream_t s) {
+static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const float* shift, int act, TV r, const ymi_tensor* out, hipStream_t s, const BnFin* fin = nullptr) {
     const int groups = (int)raw->c / 4;
     const int64_t P = ymi_pixels(raw);
     const int rows = 256 / groups;
@@ -562,6 +623,12 @@ static void launch_ssa_fixed(const ymi_tensor* raw, const float* scale, const fl
     gb = (gb + 7) / 8 * 8;             // the same number of workgroups on every XCD
     const int64_t span = ymi_xcd_span_arg(P);
     dim3 g((unsigned)gb), b(256);
+    if (fin) {
+        if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU, true>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span, *fin);
+        else if (act == YMI_ACT_GELU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_GELU, true>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span, *fin);
+        else hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_NONE, true>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span, *fin);
+        return;
+    }
     if (act == YMI_ACT_SILU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_SILU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span);
     else if (act == YMI_ACT_GELU) hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_GELU>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span);
     else hipLaunchKernelGGL((scale_shift_act_fixed_kernel<T, YMI_ACT_NONE>), g, b, 0, s, tv(raw), scale, shift, r, tv(out), groups, P, span);
@@ -641,4 +708,37 @@ static int conv_bn_act_fwd_impl(const ymi_tensor* x, const void* w_packed, int64
     rc = bn_finalize_impl(part, blocks, m, cout, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd, p2, stream);
     if (rc) return rc;
     return ymi_scale_shift_act(raw, scale, shift, act, residual, out, stream);
+}
+
+// The same Conv block with the BatchNorm statistics as fixed-point atomic sums and the finalize inside the affine pass: TWO launches
+// (igemm.hip's statistics epilogue; scale_shift_act_fixed_kernel<.., FIN>).  stat_acc: [4][2][cout] int64, ZERO on entry (the caller zeroes
+// its arena of them once per forward), garbage afterwards.  Shapes the fixed-group affine kernel does not take (cout not a multiple of 4 or
+// > 1024, unaligned tensors) are refused: the caller keeps ymi_conv2d_bn_silu_fwd for them (ymi_conv2d_bn_silu_fwd_acc_ok).
+int ymi_conv2d_fwd_statacc(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride, const ymi_tensor* y,
+                           long long* stat_acc, void* stream);
+extern "C" int ymi_conv2d_bn_silu_fwd_acc_ok(const ymi_tensor* raw, const ymi_tensor* out, const ymi_tensor* residual) {
+    if (!ymi_tensor_ok(raw) || !ymi_tensor_ok(out) || !ymi_same_shape(raw, out) || raw->dtype != out->dtype) return 0;
+    if (residual && (!ymi_tensor_ok(residual) || !ymi_same_shape(residual, out) || residual->dtype != out->dtype)) return 0;
+    const bool vec = vec4_ok(raw) && vec4_ok(out) && (!residual || vec4_ok(residual));
+    return vec && raw->c / 4 <= 256 && ymi_pixels(raw) * (raw->c / 4) < (1ll << 31);
+}
+extern "C" int ymi_conv2d_bn_silu_fwd_acc(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                                          const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                                          float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
+                                          float* save_mean, float* save_invstd, void* stat_acc, void* stream) {
+    YMI_CHECK_ARG(stat_acc && ((uintptr_t)stat_acc & 15) == 0 && ymi_conv2d_bn_silu_fwd_acc_ok(raw, out, residual) && raw->c == cout,
+                  "conv2d_bn_silu_fwd_acc: shapes the fused finalize does not take (see ymi_conv2d_bn_silu_fwd_acc_ok)");
+    YMI_CHECK_ARG((!gamma || ((uintptr_t)gamma & 15) == 0) && (!beta || ((uintptr_t)beta & 15) == 0) && (!running_mean || ((uintptr_t)running_mean & 15) == 0) &&
+                      (!running_var || ((uintptr_t)running_var & 15) == 0) && (!save_mean || ((uintptr_t)save_mean & 15) == 0) &&
+                      (!save_invstd || ((uintptr_t)save_invstd & 15) == 0),
+                  "conv2d_bn_silu_fwd_acc: 16-byte aligned per-channel vectors");
+    int rc = ymi_conv2d_fwd_statacc(x, w_packed, cout, kh, kw, stride, raw, (long long*)stat_acc, stream);
+    if (rc) return rc;
+    const BnFin fin{(const long long*)stat_acc, gamma, beta, running_mean, running_var, save_mean, save_invstd, (double)ymi_pixels(raw),
+                    ldexp(1.0, -ymi_stat_fixed_point_shift(ymi_pixels(raw))), momentum, eps};
+    TV r = residual ? tv(residual) : TV{nullptr, 0, 0, 0, 0, 0};
+    if (raw->dtype == YMI_BF16) launch_ssa_fixed<bf16_t>(raw, nullptr, nullptr, act, r, out, (hipStream_t)stream, &fin);
+    else launch_ssa_fixed<float>(raw, nullptr, nullptr, act, r, out, (hipStream_t)stream, &fin);
+    YMI_CHECK_LAUNCH("conv2d_bn_silu_fwd_acc");
+    return YMI_OK;
 }

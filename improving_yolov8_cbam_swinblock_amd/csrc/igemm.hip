@@ -82,6 +82,8 @@ struct IgemmArgs {
     const float* scale;
     const float* bias;
     float* partials;
+    long long* stat_acc;   // optional: the statistics as fixed-point atomic sums [4 replicas][2][pstride] instead of per-block rows (see the epilogue)
+    float stat_scale;      // ... in steps of 1 / stat_scale (a power of two chosen from the pixel count: ymi_stat_fixed_point_shift)
     int pstride, poff;     // statistics rows: [M block][2][pstride] floats, this problem's channels at column poff (several problems of one
                            // BatchNorm group - the two branches of a Detect level - fill one row array side by side); 0, 0: [2][Cout]
     const void* zero;
@@ -389,7 +391,21 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
 #pragma unroll
             for (int q = 0; q < WM; ++q) sum += red[(q * 2 + which) * BN + chl];
             const int ch = n0 + chl;
-            if (ch < a.Cout) a.partials[((int64_t)mb * 2 + which) * a.pstride + a.poff + ch] = sum;
+            if (ch < a.Cout) {
+                if (a.stat_acc) {
+                    // Round 5: the per-block sums leave as 64-bit FIXED-POINT atomic adds (steps of 2^-shift) into one of four replica rows, and the
+                    // consumer - the BatchNorm affine pass, a kernel boundary later - sums the replicas and finalizes in its prologue: the
+                    // separate finalize launch (and, from 1024 row blocks up, the row pre-reduction before it: 65 launches of ~5 us a step) is
+                    // gone.  Integer addition is exact and order-free, so the statistics stay bit-for-bit reproducible whatever order the
+                    // tiles finish in; a float atomic would not be.  shift = 37 - ceil(log2(pixel count)) (common.h): sums of squares up to
+                    // count * 2^24 (an r.m.s. of 4096) fit with two bits to spare, and the step is 2^-15 at 3.3 M pixels, 2^-31 at 64 - after
+                    // the division by the count below 1e-11 of the variance in either case, far under any BatchNorm eps.
+                    const long long q = __float2ll_rn(sum * a.stat_scale);
+                    __hip_atomic_fetch_add(a.stat_acc + ((int64_t)((mb & 3) * 2 + which)) * a.pstride + a.poff + ch, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    a.partials[((int64_t)mb * 2 + which) * a.pstride + a.poff + ch] = sum;
+                }
+            }
         }
     }
     if (a.vec16) {
@@ -901,7 +917,7 @@ static TileChoice choose_tile(int64_t M, int64_t cout, int64_t ktot, bool bf16) 
         t.bm = 256; t.bn = 128; t.pp = true;
     }
     const int fbm = ymi_opt(OPT_IGEMM_TILE_BM), fbn = ymi_opt(OPT_IGEMM_TILE_BN);  // force a tile (tools/conv_bench.py sweeps)
-    if (fbm > 0 && fbn > 0 && (fbn <= 32 ? cout <= 32 : true)) {
+    if (fbm > 0 && fbn > 0 && (fbn <= 32 ? cout <= 32 : true) && (fbm < 256 || (bf16 && ktot % 32 == 0))) {  // (the ping-pong tile: bf16, whole 32-deep steps)
         t.bm = fbm;
         t.bn = fbn;
         t.pp = fbm == 256;
@@ -1164,6 +1180,20 @@ extern "C" int ymi_conv2d_fwd_multi(const ymi_conv_problem* problems, int32_t n,
     if (rc) return rc;
     for (int i = 0; i < n; ++i) const_cast<ymi_conv_problem*>(problems)[i].stat_blocks = blocks[i];
     return YMI_OK;
+}
+
+// raw convolution output + BatchNorm statistics as fixed-point atomic sums (stat_acc: [4][2][cout] int64, ZERO on entry); used by
+// ymi_conv2d_bn_silu_fwd_acc (elementwise.hip)
+int ymi_conv2d_fwd_statacc(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride, const ymi_tensor* y,
+                           long long* stat_acc, void* stream) {
+    IgemmArgs a{};
+    float dummy = 0.f;  // (statistics mode is selected by a non-null row pointer; it is never written when stat_acc is set)
+    int rc = conv_fwd_args(x, w_packed, cout, kh, kw, stride, nullptr, nullptr, YMI_ACT_NONE, nullptr, y, nullptr, YMI_ACT_NONE, &dummy, &a);
+    if (rc) return rc;
+    a.partials = nullptr;
+    a.stat_acc = stat_acc;
+    a.stat_scale = (float)ldexp(1.0, ymi_stat_fixed_point_shift(ymi_pixels(y)));
+    return ymi_launch_igemm(a, x->dtype, true, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int ymi_conv2d_fwd(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,

@@ -144,7 +144,8 @@ class BaseModel(nn.Module):
         taps = getattr(self, "_taps", None)
         nb_layers = len(self.yaml["backbone"]) if taps is not None else 0
         leaf_of = {}
-        ops.new_forward_epoch()  # (weights used twice within ONE forward are shared: their gradients are never deferred)
+        # (weights used twice within ONE forward are shared: their gradients are never deferred; the BatchNorm statistics accumulators are zeroed)
+        ops.new_forward_epoch(x.device if (torch.is_tensor(x) and x.is_cuda and self.training) else None)
         self._begin_weight_arena(x)
         plan = self._graph_plan() if (self.training and torch.is_grad_enabled() and torch.is_tensor(x) and x.is_cuda) else None
         bufs = {}

@@ -31,6 +31,7 @@ HOOKS = {
     "detect_pair": True,     # Detect's sibling first convolutions as one (False: separately)
     "detect_multi": True,    # Detect's levels in lockstep, one multi-problem launch per stage (False: level by level)
     "first_conv": True,      # layer 0 through the direct kernels of csrc/first_conv.hip (False: the generic path)
+    "stat_atomics": True,    # BatchNorm statistics as fixed-point atomic sums, finalized inside the affine pass (False: per-block rows + a finalize launch)
 }
 
 
@@ -373,9 +374,36 @@ def _adoptable(params):
 # safe side: their gradients are complete when the Function returns.
 _use_epoch = [0]
 
+# BatchNorm statistics accumulators (ymi_conv2d_bn_silu_fwd_acc): every Conv block of a forward takes a [4][2][cout] int64 block that must be
+# ZERO when its GEMM starts.  A model forward starts an epoch: ONE fill zeroes the whole arena (sized by the previous epoch's demand) and the
+# blocks are handed out in call order; a block asked for outside an epoch - modules called on their own - or beyond the arena is a fresh
+# zeroed tensor.
+_stat_arena = {"buf": None, "cursor": 0, "need": 0}
 
-def new_forward_epoch():
+
+def new_forward_epoch(device=None):
     _use_epoch[0] += 1
+    a = _stat_arena
+    if device is not None and HOOKS["stat_atomics"]:
+        if a["buf"] is None or a["buf"].device != device or a["need"] > a["buf"].numel():
+            a["buf"] = torch.zeros(max(a["need"] * 2, 1 << 16), dtype=torch.int64, device=device)
+        else:
+            a["buf"].zero_()
+    else:
+        a["buf"] = None
+    a["cursor"], a["need"] = 0, 0
+
+
+def _stat_acc(cout, device):
+    a = _stat_arena
+    n = 8 * cout
+    a["need"] += n
+    buf = a["buf"]
+    if buf is not None and buf.device == device and a["cursor"] + n <= buf.numel():
+        out = buf[a["cursor"]: a["cursor"] + n]
+        a["cursor"] += n
+        return out
+    return torch.zeros(n, dtype=torch.int64, device=device)
 
 
 def _note_use(*params):
@@ -844,14 +872,26 @@ class _ConvBnAct(torch.autograd.Function):
         need = (L().ymi_conv2d_stat_blocks(m, o) * 2 * o + 2 * o) * 4
         ws = workspace(need, dev, "conv")
         res = residual
-        check(
-            L().ymi_conv2d_bn_silu_fwd(
-                _byref(as_ymi(x)), ptr(wp), o, k, k, stride, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                momentum, eps, act, _byref(as_ymi(res)) if res is not None else None, _byref(as_ymi(raw)), _byref(as_ymi(out)),
-                ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream_ptr(),
-            ),
-            "conv2d_bn_silu_fwd",
-        )
+        tres = _byref(as_ymi(res)) if res is not None else None
+        if (HOOKS["stat_atomics"] and o % 4 == 0 and L().ymi_conv2d_bn_silu_fwd_acc_ok(_byref(as_ymi(raw)), _byref(as_ymi(out)), tres)
+                and all(t is None or t.data_ptr() % 16 == 0 for t in (gamma, beta, running_mean, running_var))):
+            # statistics as fixed-point atomic sums, finalized in the affine pass's prologue: two launches instead of three (or four)
+            acc = _stat_acc(o, dev)
+            check(
+                L().ymi_conv2d_bn_silu_fwd_acc(
+                    _byref(as_ymi(x)), ptr(wp), o, k, k, stride, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                    momentum, eps, act, tres, _byref(as_ymi(raw)), _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), ptr(acc), stream_ptr(),
+                ),
+                "conv2d_bn_silu_fwd_acc",
+            )
+        else:
+            check(
+                L().ymi_conv2d_bn_silu_fwd(
+                    _byref(as_ymi(x)), ptr(wp), o, k, k, stride, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                    momentum, eps, act, tres, _byref(as_ymi(raw)), _byref(as_ymi(out)), ptr(stats[0]), ptr(stats[1]), ptr(ws), ws.numel(), stream_ptr(),
+                ),
+                "conv2d_bn_silu_fwd",
+            )
         ctx.save_for_backward(x, weight, gamma, beta, raw, stats)
         ctx.cfg = (stride, act, i, residual is not None)
         ctx.joins = (join, res_join)

@@ -172,6 +172,17 @@ int ymi_conv2d_bn_silu_fwd(const ymi_tensor* x, const void* w_packed, int64_t co
                            float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
                            float* save_mean, float* save_invstd, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same Conv block in TWO launches: the GEMM's statistics epilogue adds its per-block sums as 64-bit fixed-point atomics (exact, order-free:
+ * the statistics stay bit-reproducible) into stat_acc = [4][2][cout] int64, ZERO on entry, and the affine + activation pass finalizes them in its
+ * prologue (scale / shift per thread; saved mean / inverse deviation and the running statistics by its first workgroup) - no finalize launch.
+ * `_acc_ok`: whether the affine pass takes these tensors in that form (cout a multiple of 4 up to 1024, 4-element-aligned rows); the per-channel
+ * vectors must be 16-byte aligned.  Replaces Conv.forward, nn/modules/conv.py:69-79, as ymi_conv2d_bn_silu_fwd does. */
+int ymi_conv2d_bn_silu_fwd_acc_ok(const ymi_tensor* raw, const ymi_tensor* out, const ymi_tensor* residual);
+int ymi_conv2d_bn_silu_fwd_acc(const ymi_tensor* x, const void* w_packed, int64_t cout, int64_t kh, int64_t kw, int64_t stride,
+                               const float* gamma, const float* beta, float* running_mean, float* running_var, float momentum,
+                               float eps, int32_t act, const ymi_tensor* residual, const ymi_tensor* raw, const ymi_tensor* out,
+                               float* save_mean, float* save_invstd, void* stat_acc, void* stream);
+
 /* Backward of act(BN_train(raw)) w.r.t. raw, two passes:
  *  reduce: partial sums of dz and dz*xhat per channel, dz = dout * act'(raw*scale+shift)
  *  apply : draw = gamma*invstd*(dz - mean(dz) - xhat*mean(dz*xhat)); also dgamma, dbeta. */
