@@ -115,7 +115,7 @@ __device__ __forceinline__ float bf16_hi(uint32_t v) { return __builtin_bit_cast
 // same six-term form with the halving folded into the coefficients and the argument scalings into the constants): 11 issue slots + two
 // transcendentals per element - the vector phases of these kernels are bound by exactly this count.
 __device__ __forceinline__ float gelu_fast(float x, float* half_erfc = nullptr, float* e_out = nullptr) {
-#if YMI_MLP_ABL == 1
+#if (YMI_MLP_ABL & 1)
     if (half_erfc) *half_erfc = 0.25f;
     if (e_out) *e_out = 0.5f;
     return x;
@@ -139,7 +139,7 @@ __device__ __forceinline__ float gelu_fast(float x, float* half_erfc = nullptr, 
 
 // issue the LDS-DMA pieces of hidden chunk jc into ring stage `stage` (4 per thread): two 16 KB fragment-major images, copied linearly
 __device__ __forceinline__ void mlp_issue(const bf16_t* rows_img, const bf16_t* cols_img, int jc, char* stage, int tid, int wave) {
-#if YMI_MLP_ABL == 4
+#if (YMI_MLP_ABL & 8)
     return;
 #endif
     const bf16_t* a = rows_img + (size_t)jc * 32 * MLP_C + tid * 8;
@@ -154,17 +154,17 @@ __device__ __forceinline__ void mlp_issue(const bf16_t* rows_img, const bf16_t* 
 // lgkmcnt(0) and - at 250 live registers - recycles ONE fragment buffer: an exposed LDS round trip (~130 cycles) per 32-cycle MFMA.  So the
 // reads and their counted waits are written out (as igemm.hip's K step): four fragment buffers rotate, three reads stay in flight behind
 // every MFMA.  (Other LDS operations the compiler interleaves only make a counted wait stricter: LDS operations return in order.)
-// diagnostic builds (-DYMI_MLP_ABL=n, results wrong by design; tools/probes/r5_mlp_ablate.sh): 1 no GELU arithmetic, 2 no MFMAs, 3 no fragment reads,
-// 4 no weight copies, 5 no pre-activation stores
+// diagnostic builds (-DYMI_MLP_ABL=mask, results wrong by design; tools/probes/r5_mlp_ablate.sh): bit 1 no GELU arithmetic, 2 no MFMAs, 4 no fragment
+// reads, 8 no weight copies, 16 no pre-activation stores, 32 in-kernel phase stamps, 64 no s_setprio around the matrix phase
 #ifndef YMI_MLP_ABL
 #define YMI_MLP_ABL 0
 #endif
-#if YMI_MLP_ABL == 3
+#if (YMI_MLP_ABL & 4)
 #define MLP_RD(F, ADDR, OFF) asm volatile("" : "+v"(F) : "v"(ADDR), "n"(OFF))
 #else
 #define MLP_RD(F, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(F) : "v"(ADDR), "n"(OFF))
 #endif
-#if YMI_MLP_ABL == 2
+#if (YMI_MLP_ABL & 2)
 #define MLP_MFMA(A, B, C) (C)
 #else
 #define MLP_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
@@ -182,29 +182,15 @@ __device__ __forceinline__ void mlp_rows_product(uint32_t addr, const bf16x8 (&b
     MLP_RD(f[1], addr, 1024);
     MLP_RD(f[2], addr, 2048);
     MLP_RD(f[3], addr, 3072);
-#if YMI_MLP_ABL == 10
-    f32x16 d2;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d2[r] = 0.f;
-#endif
     static_for<0, 16>([&](auto sc) {
         constexpr int s = decltype(sc)::value;
         const uint32_t ad = addr;  // (an odr-use outside the asm operand: clang does not capture a variable it only sees there)
         MLP_WAIT((15 - s) < 3 ? (15 - s) : 3);
         asm volatile("" : "+v"(f[s & 3]));
-#if YMI_MLP_ABL == 10
-        if constexpr (s & 1) d2 = MLP_MFMA(f[s & 3], b[s], d2);
-        else d = MLP_MFMA(f[s & 3], b[s], d);
-#else
         d = MLP_MFMA(f[s & 3], b[s], d);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (s + 4 < 16) MLP_RD(f[s & 3], ad, (s + 4) * 1024);
     });
-#if YMI_MLP_ABL == 10
-#pragma unroll
-    for (int r = 0; r < 16; ++r) d[r] += d2[r];
-#endif
 }
 // acc[ct] += A(cols image: 8 tiles x 2 steps of 1 KB from `addr`) . hv[0..1]
 __device__ __forceinline__ void mlp_cols_product(uint32_t addr, const bf16x8 (&hv)[2], f32x16 (&acc)[8]) {
@@ -272,7 +258,7 @@ __device__ __forceinline__ void mlp_store_tile(f32x16 (&acc)[8], const float* bi
 // copied into ring stage c % 3 at the start of phase 2c - 2 (its previous tenant, chunk c - 3, was last read in phase 2c - 3), every
 // wave retires its pieces before the barrier that ends phase 2c - 1, and the first read is in phase 2c.
 __device__ __forceinline__ void mlp_barrier() { asm volatile("s_barrier" ::: "memory"); }
-#if YMI_MLP_ABL == 11
+#if (YMI_MLP_ABL & 32)
 // diagnostic build: s_memtime stamps of workgroup 100, waves 0 and 4, chunks 8..11, into the (otherwise unused) `mean` array of an evaluation-mode call:
 // [wave half][chunk - 8][point 0..5] = matrix phase start | after the fc2 product | after the fc1 product | past the barrier | vector work done | past the barrier
 #define MLP_STAMP(P)                                                                                                              \
@@ -292,13 +278,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];  // [3 stages][32 KB] (the output staging image afterwards: 8 x 16 KB) | b1 [hidden] floats
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#if YMI_MLP_ABL == 8
-    const int half = wave & 1;
-#elif YMI_MLP_ABL == 9
-    const int half = (wave >> 1) & 1;
-#else
-    const int half = wave >> 2;
-#endif
+    const int half = wave >> 2;  // (waves w and w + 4 share a SIMD: pairing by wave & 1 or (wave >> 1) & 1 measured 25 % slower)
     const int px = lane & 31, h = lane >> 5;
     const int row0 = blockIdx.x * MLP_BM + wave * 32;
     const int row = row0 + px;
@@ -375,7 +355,7 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
         //      fc1 of chunk jc (d1[hidden unit 8 (r >> 2) + 4 h + (r & 3)][token px] over K = 256 channels, starting at the bias)
         MLP_STAMP(0);
         if (half == 0 && jc >= 1 && jc + 1 < nch) mlp_issue(a.w1p, a.w2q, jc + 1, smem + ((jc + 1) % 3) * MLP_STAGE, tid, wave);  // (even global phase)
-        if (YMI_MLP_ABL != 6 && YMI_MLP_ABL != 7) __builtin_amdgcn_s_setprio(1);
+        if (!(YMI_MLP_ABL & 64)) __builtin_amdgcn_s_setprio(1);
         if (jc > 0) mlp_cols_product(lds0 + ((jc - 1) % 3) * MLP_STAGE + 16384, hv, acc);
         MLP_STAMP(1);
         f32x16 d1;
@@ -389,11 +369,11 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
             }
         }
         if (jc < nch) mlp_rows_product(lds0 + (jc % 3) * MLP_STAGE, uf, d1);
-        if (YMI_MLP_ABL != 6 && YMI_MLP_ABL != 7) __builtin_amdgcn_s_setprio(0);
+        if (!(YMI_MLP_ABL & 64)) __builtin_amdgcn_s_setprio(0);
         MLP_STAMP(2);
         // (odd global phase for the second half) the pieces issued one phase ago have landed: only the two pre-activation stores are younger
         if (half == 1) {
-            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (TRAIN && !(YMI_MLP_ABL & 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         mlp_barrier();
@@ -401,24 +381,22 @@ __global__ __launch_bounds__(512, 2) void swin_mlp_fwd_kernel(MlpFwdArgs a) {
         if (jc == nch) break;
         // ---- vector phase: bf16 rounding of the pre-activation (saved), exact-erf GELU, bf16 again: the B operand of fc2
         if (half == 1 && jc + 2 < nch) mlp_issue(a.w1p, a.w2q, jc + 2, smem + ((jc + 2) % 3) * MLP_STAGE, tid, wave);  // (even global phase)
-        if (YMI_MLP_ABL == 7) __builtin_amdgcn_s_setprio(1);
         uint32_t hf[8], pf[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             pf[i] = pack_bf16x2(d1[2 * i], d1[2 * i + 1]);
             hf[i] = pack_bf16x2(gelu_fast(bf16_lo(pf[i])), gelu_fast(bf16_hi(pf[i])));
         }
-        if (TRAIN && YMI_MLP_ABL != 5) {
+        if (TRAIN && !(YMI_MLP_ABL & 16)) {
             *reinterpret_cast<u32x4*>(prew + ((size_t)jc * 8 * 2 + 0) * 64 * 8) = u32x4{pf[0], pf[1], pf[2], pf[3]};
             *reinterpret_cast<u32x4*>(prew + ((size_t)jc * 8 * 2 + 1) * 64 * 8) = u32x4{pf[4], pf[5], pf[6], pf[7]};
         }
         u32x4 t0 = {hf[0], hf[1], hf[2], hf[3]}, t1 = {hf[4], hf[5], hf[6], hf[7]};
         hv[0] = __builtin_bit_cast(bf16x8, t0);
         hv[1] = __builtin_bit_cast(bf16x8, t1);
-        if (YMI_MLP_ABL == 7) __builtin_amdgcn_s_setprio(0);
         MLP_STAMP(4);
         if (half == 0) {  // (odd global phase for the first half)
-            if (TRAIN && YMI_MLP_ABL != 5) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            if (TRAIN && !(YMI_MLP_ABL & 16)) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         mlp_barrier();
