@@ -216,7 +216,9 @@ def main():
     ap.add_argument("--schedule", choices=["auto", "split", "tail"], default="auto",
                     help="graph schedule: auto = one graph on one rank, three graphs with the bucket exchanges between them on several; split = "
                          "the several-rank schedule also on one rank (what it costs without the collectives); tail = round 3's several-rank form")
-    ap.add_argument("--sustained", type=int, default=200, help="graph replays of the sustained-throughput sub-record (0: skip)")
+    ap.add_argument("--sustained", type=int, default=850,
+                    help="graph replays of the sustained-throughput sub-record (0: skip); the default keeps the device busy for >= 10 s, long enough "
+                         "for an outside 5-second GPU-busy sampler to see it")
     ap.add_argument("--forward-only", action="store_true",
                     help="profiling aid: run ONLY the train-mode forward (north_star's target metric) - warm-up + `steps` graph replays - and print "
                          "its record; under rocprofv3 --kernel-trace --stats this gives the forward's own kernel table")
@@ -270,6 +272,15 @@ def main():
 
     for _ in range(args.warmup):
         step(batch)
+    comm = None
+    if world > 1:
+        # what the exchange layer itself reports, so that a several-rank line explains itself: the world size as the process group sees it, an
+        # all-reduce of ones (= the number of ranks that took part), the flat buckets' sizes; the exposed exchange time is added after the timed steps
+        ones = torch.ones(1, dtype=torch.float32, device=dev)
+        torch.distributed.all_reduce(ones)
+        comm = {"backend": torch.distributed.get_backend(), "world_size": torch.distributed.get_world_size(), "allreduce_of_ones": float(ones.item()),
+                "bucket_bytes": [int(sum(p.numel() for p in b) * 4) for b in step.buckets.buckets]}
+        step.time_exposed_communication(True)
     lib = _lib.lib()
     timing = not args.no_kernel_timing
     instrument_inline = timing and not use_graph  # HIP events cannot be recorded inside a replayed graph
@@ -285,6 +296,11 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if comm is not None:
+        comm["exposed_ms_per_step"] = round(step.exposed_communication_ms() or 0.0, 4)
+        comm["exposed_is"] = ("compute-stream time between the end of the backbone's backward graph and the end of the wait for both buckets" if step.overlap_graphs
+                              else "the whole gradient exchange (nothing overlaps it in this schedule)")
+        step.time_exposed_communication(False)
     roof = None
     if timing:
         prof_steps = args.steps
@@ -393,6 +409,8 @@ def main():
             "model_mfma_frac": round(value * gf_both / 1e3 / (PEAK_BF16_TFLOPS * args.gpus), 4) if gf_both is not None else None,
             "loss_items": [round(float(v), 4) for v in items],
         }
+        if comm:
+            out["communication"] = comm
         if sustained:
             out["sustained"] = sustained
         if roof:

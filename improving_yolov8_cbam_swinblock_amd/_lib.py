@@ -101,6 +101,7 @@ _SIGNATURES = {
     "ymi_conv2d_bwd_weight": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp]),
     "ymi_conv2d_bwd_weight_workspace": (_sz, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i64]),
     "ymi_conv2d_bwd_weight_deferred": (_c_i32, [_TP, _TP, _c_i64, _c_i64, _c_i64, _c_i64, _c_i64, _vp, _vp, _vp, _sz, _vp, _vp]),
+    "ymi_wgrad_hold": (_c_i32, [_c_i32]),
     "ymi_wgrad_reduce_batch": (_c_i32, [_vp, _c_i32, _vp, _vp]),
     "ymi_sppf_pool3_fwd": (_c_i32, [_TP, _c_i64, _TP, _TP, _TP, _vp]),
     "ymi_sppf_pool3_bwd_workspace": (_c_i64, [_c_i64, _c_i64, _c_i64, _c_i64, _c_i32]),

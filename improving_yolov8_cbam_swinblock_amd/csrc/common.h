@@ -262,6 +262,26 @@ __device__ __forceinline__ bool ticket_is_last(unsigned* counter, unsigned last,
     __syncthreads();
     return *flag != 0;
 }
+// ---- a BatchNorm-backward final pass riding in a weight-gradient launch (round 5; wgrad.hip, reduce_bwd.hip) --------------------------
+// The final pass of a BatchNorm backward (sum <= 512 partial rows per channel, derive the apply pass's coefficients) is a 1-16 workgroup
+// kernel at a dependent-launch latency (~5.4 us, 57 times a step), and it cannot move into its producer or its consumer (a hand-off level
+// costs ~2.5 us, profiles/r05_bn_tail_ab.txt).  But the weight-gradient GEMM of the PREVIOUS layer of the backward pass is independent of it
+// and sits right beside it in the stream: with ymi_wgrad_hold(1) a deferred weight-gradient launch is held back until the next BatchNorm
+// backward has issued its reduce pass and then launched with that layer's final pass as extra workgroups at the front of its grid.
+struct YmiBnRider {
+    const float* part;  // [blocks][2][C] partial rows of the reduce pass
+    int blocks, C;
+    int nwg;            // rider workgroups at the front of the grid (a multiple of 8: the XCD dealing of the rest is unchanged); 0: none
+    float* out0;        // dbeta
+    float* out1;        // dgamma
+    const float* gamma; const float* beta; const float* mean; const float* inv;
+    const float* gamma2; const float* beta2; int split;  // second parameter set of a convolution pair (channels >= split); split == 0: one
+    float inv_count;
+    float* coef;        // [5][C]
+};
+// issue the held weight-gradient launch of `stream` with `rider` in it -> true; false when nothing is held there (the caller launches its final pass itself)
+bool ymi_wgrad_issue_held(const YmiBnRider* rider, hipStream_t stream);
+
 // a slot of 64 ticket counters for one launch (host; round-robin over 1024 slots, zero between launches)
 unsigned* ymi_ticket_slot();
 

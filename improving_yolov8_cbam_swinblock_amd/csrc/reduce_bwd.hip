@@ -606,6 +606,13 @@ static int bn_act_bwd_impl(const ymi_tensor* dout, const ymi_tensor* raw, const 
     }
     int rc = launch_chan_reduce<1>(dout, raw, gamma, beta, save_mean, save_invstd, act, (float*)workspace, &blocks, s, "bn_act_bwd(reduce)", g2);
     if (rc) return rc;
+    {   // the final pass rides in the weight-gradient launch held back for it, when there is one (common.h: YmiBnRider)
+        const YmiBnRider rider{(const float*)workspace, blocks, C, 0, dbeta, dgamma, gamma, beta, save_mean, save_invstd, g2.gamma, g2.beta, g2.split, 1.0f / (float)P, coef};
+        if (C <= 1024 && ymi_wgrad_issue_held(&rider, s)) {
+            YMI_CHECK_LAUNCH("bn_act_bwd(final, riding)");
+            return launch_bn_apply(dout, raw, draw, act, coef, s);
+        }
+    }
     // dbeta = sum dz, dgamma = sum dz*xhat, and the apply pass's coefficients
     hipLaunchKernelGGL(chan_reduce_final_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)workspace, blocks, C, dbeta, dgamma,
                        BnCoefArgs{gamma, beta, save_mean, save_invstd, 1.0f / (float)P, coef, g2});

@@ -13,6 +13,7 @@
 // (36 MB -> 18 MB written per launch at bs 32, and the batched reduce reads half as much).
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -159,8 +160,72 @@ template <> struct WFrag<float> {
 // (a 128x256 tile - 4 or 8 waves - measured 1.17-1.66x slower, profiles/r02_conv_bench_wgrad256.txt; removed in round 3)
 // BIAS: the instantiation that also forms the bias gradient's partials (its own code object: the 4 * TR accumulator registers and the branch
 // cost the bias-free launches 3-4 % when they were a run-time option of one kernel)
+// the final pass of a BatchNorm backward as a rider (common.h: YmiBnRider): workgroup w sums the partial rows of channels [32 w, 32 w + 32) - 8 row
+// slices x 32 channels per workgroup, eight loads in flight per lane, combined in double in a fixed order - and writes dbeta / dgamma and the apply
+// pass's coefficients (reduce_bwd.hip: chan_reduce_final_kernel is the same pass as its own launch)
+__device__ __forceinline__ void wgrad_rider_final(const YmiBnRider& r, int w, char* smem) {
+    // BIT FOR BIT chan_reduce_final_kernel's arithmetic (reduce_bwd.hip: 32 row slices per channel, four float chains each, combined in double in
+    // slice order), so a step gives the same gradients with the final passes riding or not: a thread plays four of the 32 slices
+    double* red = reinterpret_cast<double*>(smem);  // [2][32][33]
+    const int cl = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int c = w * 32 + cl;
+    if (w * 32 >= r.C) return;  // (padding workgroups of the rider block: uniform)
+#pragma unroll
+    for (int es = 0; es < 4; ++es) {
+        const int slice = grp * 4 + es;
+        double s0 = 0.0, s1 = 0.0;
+        if (c < r.C) {
+            float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f, c0 = 0.f, c1 = 0.f, d0 = 0.f, d1 = 0.f;
+            int b = slice;
+            for (; b + 96 < r.blocks; b += 128) {
+                a0 += r.part[((int64_t)b * 2 + 0) * r.C + c];
+                a1 += r.part[((int64_t)b * 2 + 1) * r.C + c];
+                b0 += r.part[((int64_t)(b + 32) * 2 + 0) * r.C + c];
+                b1 += r.part[((int64_t)(b + 32) * 2 + 1) * r.C + c];
+                c0 += r.part[((int64_t)(b + 64) * 2 + 0) * r.C + c];
+                c1 += r.part[((int64_t)(b + 64) * 2 + 1) * r.C + c];
+                d0 += r.part[((int64_t)(b + 96) * 2 + 0) * r.C + c];
+                d1 += r.part[((int64_t)(b + 96) * 2 + 1) * r.C + c];
+            }
+            for (; b < r.blocks; b += 32) {
+                a0 += r.part[((int64_t)b * 2 + 0) * r.C + c];
+                a1 += r.part[((int64_t)b * 2 + 1) * r.C + c];
+            }
+            s0 = ((double)a0 + (double)b0) + ((double)c0 + (double)d0);
+            s1 = ((double)a1 + (double)b1) + ((double)c1 + (double)d1);
+        }
+        red[(0 * 32 + slice) * 33 + cl] = s0;
+        red[(1 * 32 + slice) * 33 + cl] = s1;
+    }
+    __syncthreads();
+    if (grp == 0 && c < r.C) {
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) {
+            a0 += red[(0 * 32 + q) * 33 + cl];
+            a1 += red[(1 * 32 + q) * 33 + cl];
+        }
+        if (r.out0) r.out0[c] = (float)a0;
+        if (r.out1) r.out1[c] = (float)a1;
+        if (r.coef) {
+            const bool second = r.split > 0 && c >= r.split;
+            const float* gp = second ? r.gamma2 : r.gamma;
+            const float* bp = second ? r.beta2 : r.beta;
+            const int pc = second ? c - r.split : c;
+            const float ga = gp ? gp[pc] : 1.0f, be = bp ? bp[pc] : 0.0f;
+            const float p0 = r.inv[c], p1 = -r.mean[c] * p0;
+            const float k1 = (float)a0 * r.inv_count, k2 = (float)a1 * r.inv_count;
+            r.coef[0 * r.C + c] = p0 * ga;
+            r.coef[1 * r.C + c] = p1 * ga + be;
+            r.coef[2 * r.C + c] = ga * p0;
+            r.coef[3 * r.C + c] = ga * p0 * p0 * k2;
+            r.coef[4 * r.C + c] = ga * p0 * (k1 + p1 * k2);
+        }
+    }
+}
+
 template <typename T, int NS, int BM, bool BIAS = false>
-__global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a) {
+__global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a, YmiBnRider rider) {
     constexpr int BNW = WG_BN, NT = 256;
     constexpr int CH = ElemTraits<T>::CH;
     constexpr int ES = (int)sizeof(T);
@@ -188,8 +253,12 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
     // eighth of the pixel order (common.h, XCD ownership of the pixel axis) - the BatchNorm apply pass wrote those dY rows from
     // this XCD a launch ago (round 3 dealt z = 8 i + xcd: every split's rows came from the other seven L2s).
     int bx, by, bz;
+    if (rider.nwg && (int)blockIdx.x < rider.nwg) {  // (only in the 1-D XCD-mapped grid; workgroup-uniform)
+        wgrad_rider_final(rider, (int)blockIdx.x, smem);
+        return;
+    }
     if (a.xcd_map) {
-        const int id = blockIdx.x, xcd = id & 7, seq = id >> 3, nxy = a.nx * a.ny;
+        const int id = (int)blockIdx.x - rider.nwg, xcd = id & 7, seq = id >> 3, nxy = a.nx * a.ny;
         const int zi = seq / nxy, t = seq - zi * nxy;
         const int spx = (a.splits + 7) >> 3;
         bz = xcd * spx + zi;
@@ -561,6 +630,76 @@ extern "C" size_t ymi_conv2d_bwd_weight_workspace(int64_t m_rows, int64_t cout, 
 static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw, int64_t stride,
                       float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, ymi_wgrad_pending* pending, void* stream);
 
+// ---- a launch, possibly held back (common.h: YmiBnRider) -------------------------------------------------------------------------------
+struct WgradLaunch {
+    WgradArgs a;
+    dim3 grid;
+    int bm;
+    bool bf16;
+    hipStream_t s;
+    double flop, bytes;
+};
+static void wgrad_launch(const WgradLaunch& h, const YmiBnRider* rider) {
+    YmiBnRider r{};
+    dim3 grid = h.grid;
+    if (rider && h.a.xcd_map) {  // rider workgroups at the front of the 1-D grid
+        r = *rider;
+        r.nwg = ((rider->C + 31) / 32 + 7) / 8 * 8;
+        grid.x += (unsigned)r.nwg;
+    }
+    const WgradArgs& a = h.a;
+    hipStream_t s = h.s;
+    int prof = -1;
+    if (ymi_prof_enabled()) prof = ymi_prof_start(s, 1, h.flop, h.bytes, h.bf16 ? 2500.0 : 157.3);
+#define YMI_WG_LAUNCH(T, BMV, LDS)                                                                                   \
+    do {                                                                                                            \
+        if (a.bias_slab) hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, true>), grid, dim3(256), (LDS), s, a, r);       \
+        else hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, false>), grid, dim3(256), (LDS), s, a, r);                  \
+    } while (0)
+    if (h.bf16) {
+        // two LDS stages (deeper rings measured equal: same bytes in flight per CU)
+        if (h.bm == 128) YMI_WG_LAUNCH(bf16_t, 128, (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS);
+        else if (h.bm == 32) YMI_WG_LAUNCH(bf16_t, 32, (size_t)2 * (WG_BK * (32 + WG_BN) * 2) + WG_STAMP_LDS);
+        else YMI_WG_LAUNCH(bf16_t, 64, (size_t)2 * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS);
+    } else {
+        const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        YMI_WG_LAUNCH(float, 64, lds);
+    }
+#undef YMI_WG_LAUNCH
+    ymi_prof_stop(s, prof);
+}
+static std::mutex g_hold_mu;
+static bool g_hold_on = false, g_held_valid = false;
+static WgradLaunch g_held;
+static void wgrad_flush_held_locked() {
+    if (g_held_valid) {
+        g_held_valid = false;
+        wgrad_launch(g_held, nullptr);
+    }
+}
+bool ymi_wgrad_issue_held(const YmiBnRider* rider, hipStream_t stream) {
+    std::lock_guard<std::mutex> lk(g_hold_mu);
+    if (!g_held_valid || g_held.s != stream || !g_held.a.xcd_map) return false;
+    g_held_valid = false;
+    wgrad_launch(g_held, rider);
+    return true;
+}
+// mode 1: hold deferred weight-gradient launches for riders; 0: stop holding (a held launch is issued as it is); 2: forget a held launch (after a
+// backward pass that raised: its operands are gone), the mode stays
+extern "C" int ymi_wgrad_hold(int32_t mode) {
+    std::lock_guard<std::mutex> lk(g_hold_mu);
+    if (mode == 2) {
+        g_held_valid = false;
+        return YMI_OK;
+    }
+    YMI_CHECK_ARG(mode == 0 || mode == 1, "wgrad_hold: mode 0, 1 or 2");
+    if (mode == 0) wgrad_flush_held_locked();
+    g_hold_on = mode == 1;
+    return hipGetLastError() == hipSuccess ? YMI_OK : YMI_ELAUNCH;
+}
+
 extern "C" int ymi_conv2d_bwd_weight(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
                                      int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes, void* stream) {
     return wgrad_impl(x, dy, cout_real, cin_real, kh, kw, stride, dw_oihw, dbias, workspace, workspace_bytes, nullptr, stream);
@@ -588,6 +727,10 @@ __global__ void wgrad_table_write_kernel(WgradTableChunk c, int n, ymi_wgrad_pen
 extern "C" int ymi_wgrad_reduce_batch(const ymi_wgrad_pending* host_records, int32_t n, ymi_wgrad_pending* device_table, void* stream) {
     YMI_CHECK_ARG(host_records && device_table && n > 0, "wgrad_reduce_batch: args");
     hipStream_t s = (hipStream_t)stream;
+    {   // a launch still held back for a rider (ymi_wgrad_hold): its slabs are summed below
+        std::lock_guard<std::mutex> lk(g_hold_mu);
+        wgrad_flush_held_locked();
+    }
     int64_t total = 0;
     for (int base = 0; base < n; base += WG_TABLE_CHUNK) {
         WgradTableChunk c{};
@@ -649,30 +792,21 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     dim3 grid((unsigned)a.nx, (unsigned)a.ny, (unsigned)p.splits);
     if (a.xcd_map) grid = dim3((unsigned)(8 * ((p.splits + 7) / 8) * a.nx * a.ny), 1, 1);
     hipStream_t s = (hipStream_t)stream;
-    int prof = -1;
-    if (ymi_prof_enabled()) {
-        const double es = (double)ymi_esize(x->dtype);
-        const double bytes = ((double)ymi_pixels(x) * x->c + (double)mpix * dy->c) * es + (double)dy->c * ng * 4.0;
-        prof = ymi_prof_start(s, 1, 2.0 * (double)mpix * (double)dy->c * (double)ng, bytes, x->dtype == YMI_BF16 ? 2500.0 : 157.3);
+    const double es = (double)ymi_esize(x->dtype);
+    WgradLaunch h{a, grid, bm, bf16, s, 2.0 * (double)mpix * (double)dy->c * (double)ng,
+                  ((double)ymi_pixels(x) * x->c + (double)mpix * dy->c) * es + (double)dy->c * ng * 4.0};
+    {
+        std::lock_guard<std::mutex> lk(g_hold_mu);
+        wgrad_flush_held_locked();  // (at most one launch is held)
+        if (pending && g_hold_on && a.xcd_map) {
+            // held back: the next BatchNorm backward of this stream issues it with its final pass riding along (or the next deferred call / the
+            // batched slab sum / ymi_wgrad_hold(0) as it is).  The caller keeps operands and workspace alive until the slab sum anyway.
+            g_held = h;
+            g_held_valid = true;
+        } else {
+            wgrad_launch(h, nullptr);
+        }
     }
-#define YMI_WG_LAUNCH(T, BMV, LDS)                                                                                   \
-    do {                                                                                                            \
-        if (a.bias_slab) hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, true>), grid, dim3(256), (LDS), s, a);          \
-        else hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, false>), grid, dim3(256), (LDS), s, a);                     \
-    } while (0)
-    if (bf16) {
-        // two LDS stages (deeper rings measured equal: same bytes in flight per CU)
-        if (bm == 128) YMI_WG_LAUNCH(bf16_t, 128, (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS);
-        else if (bm == 32) YMI_WG_LAUNCH(bf16_t, 32, (size_t)2 * (WG_BK * (32 + WG_BN) * 2) + WG_STAMP_LDS);
-        else YMI_WG_LAUNCH(bf16_t, 64, (size_t)2 * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS);
-    } else {
-        const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        YMI_WG_LAUNCH(float, 64, lds);
-    }
-#undef YMI_WG_LAUNCH
-    ymi_prof_stop(s, prof);
     YMI_CHECK_LAUNCH("wgrad");
     const int64_t elems = (int64_t)a.CoutP * a.NG;
     if (pending) {  // the slab sum is left to ymi_wgrad_reduce_batch (one launch for every layer of the backward pass)

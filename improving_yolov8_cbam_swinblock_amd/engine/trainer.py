@@ -117,6 +117,7 @@ class TrainStep:
         self._static_items = None
         self._graph_grads = None
         self._seed = None
+        self._comm_events = None  # time_exposed_communication(): [(event after the backward's last graph, event after the wait for the buckets)]
 
     def __call__(self, batch):
         if not self.use_graph:
@@ -163,7 +164,12 @@ class TrainStep:
             self.buckets.start(0)       # the head's gradient sums travel ...
             self._graph2.replay()       # ... while the backbone's backward runs
             self.buckets.start(1)
+            ev = self._comm_event_pair()
+            if ev:
+                ev[0].record()          # (completes when the backbone's backward does)
             self.buckets.wait_all(divide=False)  # the current stream waits for both; .grad = the flat buffers' slices
+            if ev:
+                ev[1].record()          # (completes once the compute stream may go on: the gap is communication nothing hid)
             self._graph3.replay()
             if self.ema is not None:
                 self.opt.count_updates(+1)
@@ -193,7 +199,7 @@ class TrainStep:
         leaves = [leaf for _, leaf in pairs]
         # torch.autograd.grad, not backward(): the leaves are channel slices of concat buffers (not dense), and AccumulateGrad would
         # re-lay every gradient it stores for them out as NCHW-contiguous copies; captured gradients are handed over as they are
-        with ops.deferred_wgrad(True):
+        with ops.deferred_wgrad(True), ops.wgrad_riders(self.use_graph):
             grads = torch.autograd.grad([loss], leaves + self._head_params, [self._seed], allow_unused=True)
         return items, list(grads[len(leaves):]), [(orig, g) for (orig, _), g in zip(pairs, grads[: len(leaves)])]
 
@@ -214,7 +220,7 @@ class TrainStep:
                 g = ops._accumulate(g, adds) if adds else g  # (no backbone consumer left to arrive: the head's gradient is the total)
             roots.append(orig)
             grads.append(g)
-        with ops.deferred_wgrad(True):
+        with ops.deferred_wgrad(True), ops.wgrad_riders(self.use_graph):
             torch.autograd.backward(roots, grads)
 
     def _pack(self, bi, params, grads):
@@ -263,13 +269,37 @@ class TrainStep:
         # sum, the multiplication and their backward nodes would be five one-element launches
         if self._seed is None or self._seed.device != loss.device:
             self._seed = torch.full((3,), float(self.world), dtype=torch.float32, device=loss.device)
-        with ops.deferred_wgrad(True), ops.async_wgrad(ASYNC_WGRAD and not self.use_graph):  # joins the side stream on exit
+        # (captured steps run on one stream: there the BatchNorm-backward final passes ride in the weight-gradient launches, ops.wgrad_riders)
+        with ops.deferred_wgrad(True), ops.async_wgrad(ASYNC_WGRAD and not self.use_graph), ops.wgrad_riders(self.use_graph):  # joins the side stream on exit
             torch.autograd.backward([loss], [self._seed])
         return items
 
     def _reduce_and_update(self, grads_of=None):
+        ev = self._comm_event_pair()
+        if ev:
+            ev[0].record()
         self.buckets.finish(grads_of, divide=False)  # world > 1: leaves the SUM in .grad (views of the flat buckets); the step scales by 1 / world
+        if ev:
+            ev[1].record()
         self.opt.step(grads_of if self.world == 1 else None)
+
+    # ---- exposed-communication probe (bench.py's several-rank line) ---------------------------------------------------------------
+    def time_exposed_communication(self, on=True):
+        """from now on every step brackets its wait for the gradient exchange with two events on the compute stream: what elapses between them
+        is exchange time the backward did not hide (three-graph schedule: behind the backbone's backward; tail / eager: the whole exchange)."""
+        self._comm_events = [] if on else None
+
+    def _comm_event_pair(self):
+        if self._comm_events is None or self.world == 1:
+            return None
+        pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self._comm_events.append(pair)
+        return pair
+
+    def exposed_communication_ms(self):
+        """mean milliseconds per step between the two events (call after a synchronize); None when nothing was timed"""
+        ev = self._comm_events or []
+        return sum(a.elapsed_time(b) for a, b in ev) / len(ev) if ev else None
 
     def eager_step(self, batch):
         items = self._forward_backward(batch)

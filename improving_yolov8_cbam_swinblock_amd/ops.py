@@ -32,6 +32,7 @@ HOOKS = {
     "detect_multi": True,    # Detect's levels in lockstep, one multi-problem launch per stage (False: level by level)
     "first_conv": True,      # layer 0 through the direct kernels of csrc/first_conv.hip (False: the generic path)
     "stat_atomics": True,    # BatchNorm statistics as fixed-point atomic sums, finalized inside the affine pass (False: per-block rows + a finalize launch)
+    "wgrad_rider": True,     # BatchNorm-backward final passes ride in the previous layer's weight-gradient launch (False: their own launches)
 }
 
 
@@ -521,6 +522,27 @@ class deferred_wgrad:
         return False
 
 
+class wgrad_riders:
+    """context manager around a backward pass with deferred weight gradients on ONE stream (engine.trainer.TrainStep's captured steps): the
+    library holds each deferred weight-gradient launch back until the next BatchNorm backward, whose final pass then rides in it
+    (include/ymi.h: ymi_wgrad_hold).  Leaving the context issues a launch still held."""
+
+    def __init__(self, enabled=True):
+        self.enabled = bool(enabled) and HOOKS["wgrad_rider"]
+
+    def __enter__(self):
+        if self.enabled:
+            check(L().ymi_wgrad_hold(1), "wgrad_hold")
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            check(L().ymi_wgrad_hold(2 if exc[0] is not None else 0), "wgrad_hold")
+            if exc[0] is not None:
+                L().ymi_wgrad_hold(0)
+        return False
+
+
 def set_wgrad_deferred(flag):
     """process-wide switch (tests / tools); prefer the `deferred_wgrad` context manager."""
     _deferred["on"] = bool(flag)
@@ -585,6 +607,8 @@ def _wgrad_deferred(x, dy, cout, cin, k, stride, want_bias, owner=None, dw=None,
     if _deferred["task"] != task:
         # first deferred gradient of this pass.  Records of an earlier pass whose end-of-pass callback never ran (the engine
         # drops callbacks when a backward raises) are stale: their gradient tensors are gone - discard them.
+        if _deferred["records"]:
+            L().ymi_wgrad_hold(2)  # (a launch the library still holds back for a rider belongs to that pass too: its operands are gone)
         _deferred["records"], _deferred["keep"], _deferred["owners"], _deferred["bias"] = [], [], [], []
         torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrads)
         _deferred["task"] = task

@@ -248,6 +248,12 @@ typedef struct ymi_wgrad_pending {
 int ymi_conv2d_bwd_weight_deferred(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_real, int64_t cin_real, int64_t kh, int64_t kw,
                                    int64_t stride, float* dw_oihw, float* dbias, void* workspace, size_t workspace_bytes,
                                    ymi_wgrad_pending* pending, void* stream);
+/* Riders.  mode 1: a deferred weight-gradient launch (ymi_conv2d_bwd_weight_deferred) is HELD BACK - at most one - until the next BatchNorm
+ * backward on the same stream (ymi_bn_act_bwd / _pair) has issued its reduce pass; it is then launched with that layer's final pass (the sum of
+ * the partial rows, the apply pass's coefficients: a 1-16 workgroup kernel at a dependent-launch latency otherwise) as extra workgroups of its own
+ * grid.  The next deferred call, ymi_wgrad_reduce_batch and mode 0 issue a held launch as it is; mode 2 forgets it (after a backward pass that
+ * raised).  The caller keeps operands and workspace of a deferred launch alive until the batched slab sum in any case.  No reference counterpart. */
+int ymi_wgrad_hold(int32_t mode);
 /* host_records: the n records of the pending layers (HOST memory; first_block is filled in here); device_table: device
  * scratch for n records.  The records reach the device inside kernel arguments (no host staging: graph-capturable). */
 int ymi_wgrad_reduce_batch(const ymi_wgrad_pending* host_records, int32_t n, ymi_wgrad_pending* device_table, void* stream);

@@ -167,3 +167,61 @@ def test_multi_problem_entry_points_equal_the_single_problem_ones(dtype):
     torch.cuda.synchronize()
     for a, b in zip(multi, single):
         assert rel(a, b) <= (1e-6 if dtype == torch.float32 else 4e-3), (tuple(b.shape), rel(a, b))
+
+
+def test_lockstep_detect_vs_matched_oracle_at_s_scale_widths():
+    """ops.detect_train (the DEFAULT training path of Detect: sibling convolutions merged, the three levels in lockstep) held DIRECTLY to the
+    quantisation-matched oracle at the s-scale widths of the benchmark model (128 / 256 / 512, nc = 1; head.py:36-76): every map, every input
+    gradient, every parameter gradient - not through the level-by-level HIP path and not only inside whole-model tests."""
+    import oracle.modules as OM
+    from oracle import quant
+    from improving_yolov8_cbam_swinblock_amd import ops
+
+    nc, ch, sizes = 1, (128, 256, 512), ((20, 20), (10, 10), (5, 5))
+    torch.manual_seed(21)
+    OM.Detect.legacy = True
+    o = OM.Detect(nc, ch)
+    o.stride = torch.tensor([8.0, 16.0, 32.0])
+    o.bias_init()
+    for b in o.modules():
+        if isinstance(b, torch.nn.BatchNorm2d):
+            b.eps, b.momentum = 1e-3, 0.03
+            b.weight.data.uniform_(0.5, 1.5)
+            b.bias.data.normal_(0, 0.3)
+    quant.round_weights_(o)
+    m = _detect(0, nc, ch)
+    m.load_state_dict(o.state_dict())
+    o.train()
+    g = torch.Generator().manual_seed(8)
+    q = lambda t: t.bfloat16().float()
+    xs = [q(torch.randn(4, c, h, w, generator=g)) for c, (h, w) in zip(ch, sizes)]
+    gys = [q(torch.randn(4, 64 + nc, h, w, generator=g) * 0.1) for (h, w) in sizes]
+    xo = [x.clone().requires_grad_(True) for x in xs]
+    with quant.storage(torch.bfloat16):
+        yo = o(xo)
+        go = torch.autograd.grad(yo, xo + [p for p in o.parameters() if p.requires_grad], gys)
+    calls = []
+    orig = ops.detect_train
+    ops.detect_train = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        xg = [x.to(dev()).requires_grad_(True) for x in xs]
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            box, cls = m.forward_split(xg)
+        outs, gouts = [], []
+        for b, c, gy in zip(box, cls, gys):
+            outs += [b, c]
+            gouts += [gy[:, :64].to(dev()).to(b.dtype), gy[:, 64:].to(dev()).to(c.dtype)]
+        params = [p for p in m.parameters() if p.requires_grad]
+        gg = torch.autograd.grad(outs, xg + params, gouts)
+    finally:
+        ops.detect_train = orig
+    assert calls, "the lockstep path did not run"
+    names_o = [n for n, p in o.named_parameters() if p.requires_grad]
+    names_m = [n for n, p in m.named_parameters() if p.requires_grad]
+    assert names_o == names_m
+    for lvl, (b, c, y) in enumerate(zip(box, cls, yo)):
+        assert rel(b, y[:, :64]) <= 4e-3 and rel(c, y[:, 64:]) <= 4e-3, (lvl, rel(b, y[:, :64]), rel(c, y[:, 64:]))   # FWD_BOUND of test_gpu_bf16_matched.py
+    errs = {f"x{i}": rel(gg[i], q(go[i])) for i in range(3)}
+    errs.update({n: rel(a, b) for n, a, b in zip(names_m, gg[3:], go[3:])})
+    print("\n[matched lockstep Detect] worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+    assert all(e <= 1e-2 for e in errs.values()), {k: v for k, v in errs.items() if v > 1e-2}   # GRAD_BOUND

@@ -214,6 +214,10 @@ def test_bench_two_ranks_gloo_as_a_child_process():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["parallelism"] == "dp2" and d["config"]["global_batch"] == 4 and d["config"]["backend"] == "gloo"
     assert d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak" and all(v == v for v in d["loss_items"])
+    # the several-rank line explains itself: what the process group reports, an all-reduce of ones, the buckets, the exchange time nothing hid
+    c = d["communication"]
+    assert c["world_size"] == 2 and c["allreduce_of_ones"] == 2.0 and c["backend"] == "gloo"
+    assert len(c["bucket_bytes"]) == 2 and sum(c["bucket_bytes"]) > 1 << 20 and c["exposed_ms_per_step"] >= 0.0
 
 
 def test_frozen_mid_network_conv_gets_no_deferred_weight_gradient():
@@ -262,3 +266,41 @@ def test_weight_used_twice_in_one_pass_accumulates_both_gradients():
 
     g0, g1 = run(False), run(True)
     assert rel(g1, g0) <= 1e-5, rel(g1, g0)
+
+
+def test_bn_backward_final_passes_riding_in_weight_gradient_launches():
+    """ops.wgrad_riders: every deferred weight-gradient launch is held back until the next BatchNorm backward, whose final pass (dgamma / dbeta /
+    the apply pass's coefficients) then rides in it as extra workgroups.  The rider repeats chan_reduce_final_kernel's arithmetic bit for bit, so the
+    gradients are IDENTICAL to a pass with the final passes as their own launches; a raised pass leaves no launch behind."""
+    from improving_yolov8_cbam_swinblock_amd import _lib as L, ops
+
+    model, batch = _small_model()
+    stats = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    with ops.deferred_wgrad(True):
+        _backward(model, batch)
+    ref = _grads(model)
+
+    def ride():
+        model.zero_grad(set_to_none=True)
+        model.load_state_dict(stats, strict=False)
+        with ops.deferred_wgrad(True), ops.wgrad_riders(True):
+            _backward(model, batch)
+        return _grads(model)
+
+    got = ride()
+    assert set(got) == set(ref) and len(ref) > 100
+    bad = [n for n in ref if not torch.equal(got[n], ref[n])]
+    assert not bad, bad[:5]
+    again = ride()
+    assert all(torch.equal(again[n], got[n]) for n in got)
+    # a pass that raises inside the riders context: the held launch is forgotten, the next pass is unaffected
+    model.zero_grad(set_to_none=True)
+    model.load_state_dict(stats, strict=False)
+    with pytest.raises(RuntimeError, match="boom"):
+        with ops.deferred_wgrad(True), ops.wgrad_riders(True):
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                loss, _ = model(batch)
+            h = loss.register_hook(lambda g: (_ for _ in ()).throw(RuntimeError("boom")))
+            loss.sum().backward()
+    third = ride()
+    assert all(torch.equal(third[n], got[n]) for n in got)
