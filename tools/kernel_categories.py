@@ -12,10 +12,13 @@ CATS = [
     ("bn_bwd", ("bn_act_bwd", "chan_reduce")),
     ("pool", ("pool", "sppf_")),
     ("cbam", ("cbam",)),
+    ("swin_mlp", ("swin_mlp_",)),   # round 5: the fused LayerNorm-2 + MLP kernels (forward, backward data path, weight-image pack)
+    ("first_conv", ("first_conv_kernel",)),
     ("swin", ("window", "layernorm", "attn", "gelu", "token")),
     ("loss", ("decode_kernel", "metric_kernel", "topk_kernel", "assign_kernel", "posmax", "finalize_kernel", "loss_kernel", "loss_final", "targets_kernel")),
     ("move", ("move_kernel", "nchw_to", "nhwc_to", "upsample", "add_inplace", "copy_kernel")),
     ("pack", ("pack_",)),
+    ("optimizer", ("opt_",)),
 ]
 
 
