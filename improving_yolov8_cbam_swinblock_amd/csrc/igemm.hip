@@ -746,6 +746,9 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
         static_assert(NTHR == 512 && NS == 3 && FAST && std::is_same<T, bf16_t>::value && WM == 4, "ping-pong form: 512 threads, 3 stages, bf16");
         const int half = wave_all >> 2;  // 0: rows 0..BM/2-1 (starts first), 1: the other rows, half a step behind
         bf16x8 wf[CPR / 4][TN], xf[CPR / 4][TM];
+#ifdef YMI_PP_STAGGER  // diagnostic: the workgroup in the upper wave slots of its SIMDs starts YMI_PP_STAGGER * 64 cycles late
+        if (__builtin_amdgcn_s_getreg(4 | (3 << 11)) & 2) __builtin_amdgcn_s_sleep(YMI_PP_STAGGER);
+#endif
         issue(0);
         if (nkt > 1) issue(1);
         // step 0 (and only it) has landed when the pieces of step 1 may still be outstanding
@@ -767,6 +770,9 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
 #ifndef YMI_PP_ALLMEM
 #define YMI_PP_ALLMEM 0
 #endif
+#ifndef YMI_IGEMM_ABL  // diagnostic builds (results wrong by design): bit 1 no LDS-DMA pieces inside the K loop, 2 no MFMAs, 4 no fragment reads
+#define YMI_IGEMM_ABL 0
+#endif
         constexpr int NMEM = YMI_PP_ALLMEM ? NA + NB : NA;  // pieces issued in the memory phase (pieces are numbered A rows first)
         constexpr int NPC = NA + NB;       // pieces per wave and step
         constexpr int NM = (CPR / 4) * TN * TM;
@@ -774,6 +780,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             constexpr int p = decltype(pc)::value;
             char* Ad = smem + s * STAGE;
             char* Bd = Ad + BM * ROWB;
+            if (YMI_IGEMM_ABL & 1) return;
             if constexpr (p < NA) __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[p], (lptr_t)(Ad + (p * LT + wave * 64) * 16), 16, 0, 0);
             else __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[p - NA], (lptr_t)(Bd + ((p - NA) * LT + wave * 64) * 16), 16, 0, 0);
         };
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             // ---- memory phase of step kt
             YMI_STAMP(kt);  // 0: phase start
             const char* As = smem + (kt % NS) * STAGE;
-            Mma<T>::template read_frags<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, wf, xf);
+            if (!(YMI_IGEMM_ABL & 4) || kt == 0) Mma<T>::template read_frags<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, wf, xf);
             if (more) static_for<0, NMEM>([&](auto pc) { load_piece(sn, pc); });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             YMI_STAMP(kt);  // 1: fragments in registers, A pieces issued
@@ -818,7 +825,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
                     static_for<0, TM>([&](auto tmc) {
                         constexpr int tm = decltype(tmc)::value;
                         constexpr int q = (ks * TN + tn) * TM + tm;
-                        acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+                        if (!(YMI_IGEMM_ABL & 2)) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
                         static_for<NMEM, NPC>([&](auto pc) {  // weight piece j after MFMA 4 + 6 j
                             constexpr int pp = decltype(pc)::value;
                             if constexpr (q == 4 + 6 * (pp - NMEM) && q < NM) {
