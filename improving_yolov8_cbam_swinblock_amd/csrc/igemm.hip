@@ -770,6 +770,12 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
 #ifndef YMI_PP_ALLMEM
 #define YMI_PP_ALLMEM 0
 #endif
+#ifndef YMI_PP_ADV_MEM
+#define YMI_PP_ADV_MEM 0
+#endif
+#ifndef YMI_PP_PRIO
+#define YMI_PP_PRIO 0
+#endif
 #ifndef YMI_IGEMM_ABL  // diagnostic builds (results wrong by design): bit 1 no LDS-DMA pieces inside the K loop, 2 no MFMAs, 4 no fragment reads
 #define YMI_IGEMM_ABL 0
 #endif
@@ -802,6 +808,9 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             YMI_STAMP(kt);  // 0: phase start
             const char* As = smem + (kt % NS) * STAGE;
             if (!(YMI_IGEMM_ABL & 4) || kt == 0) Mma<T>::template read_frags<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, wf, xf);
+#if YMI_PP_ADV_MEM
+            if (kt > 0 && kt + 1 < nkt) advance();  // the bookkeeping of step kt-1's pieces, behind the reads instead of behind the MFMAs
+#endif
             if (more) static_for<0, NMEM>([&](auto pc) { load_piece(sn, pc); });
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             YMI_STAMP(kt);  // 1: fragments in registers, A pieces issued
@@ -814,6 +823,9 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             // ---- compute phase of step kt
             YMI_STAMP(kt);  // 2: past the barrier that ends the memory phase
             __builtin_amdgcn_sched_barrier(0);
+#if YMI_PP_PRIO
+            __builtin_amdgcn_s_setprio(1);
+#endif
             static_for<0, CPR / 4>([&](auto ksc) {
                 constexpr int ks = decltype(ksc)::value;
 #pragma unroll
@@ -838,7 +850,12 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
                 });
             });
             __builtin_amdgcn_sched_barrier(0);
+#if YMI_PP_PRIO
+            __builtin_amdgcn_s_setprio(0);
+#endif
+#if !YMI_PP_ADV_MEM
             if (more) advance();
+#endif
             YMI_STAMP(kt);  // 3: MFMAs issued, pointers advanced
             if (half == 0) {
                 if (more) wait_vmcnt_barrier<NPC>();  // everything older than step kt+2's pieces
