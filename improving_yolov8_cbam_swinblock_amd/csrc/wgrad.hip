@@ -70,6 +70,12 @@ constexpr int WG_BM = 64;    // rows  (co)
 constexpr int WG_BN = 128;   // cols  ((tap, ci))
 constexpr int WG_BK = 32;    // pixels per K step (64 was measured 10-15 % slower: half as many resident workgroups per CU)
 
+#ifndef YMI_WGRAD_ABL  // diagnostic builds (results wrong by design): bit 1 no LDS-DMA pieces inside the K loop, 2 no MFMAs, 4 no fragment reads, 8 no pixel walk, 16 no slab stores
+#define YMI_WGRAD_ABL 0
+#endif
+#ifndef YMI_WGRAD_DIRECT_SLAB  // 1: bfloat16 slabs stored straight from the accumulators (the form before round 5; A/B builds)
+#define YMI_WGRAD_DIRECT_SLAB 0
+#endif
 #ifndef YMI_WGRAD_WAVES
 #define YMI_WGRAD_WAVES 5  // waves per SIMD the register allocation must allow (the kernel is latency-bound: occupancy pays)
 #endif
@@ -110,15 +116,24 @@ template <> struct WFrag<bf16_t> {
             const char* Xk = Xs + ks * 32 * BNW * 2;
             bf16x8 af[TR], bfr[TC];
 #pragma unroll
-            for (int t = 0; t < TR; ++t) af[t] = load<YSwz<BM>::SW>(Yk, BM * 2, r0 + t * 16, lane);  // by the dY image's row width
+            for (int t = 0; t < TR; ++t) af[t] = (YMI_WGRAD_ABL & 4) ? bf16x8{} : load<YSwz<BM>::SW>(Yk, BM * 2, r0 + t * 16, lane);  // by the dY image's row width
             // (512-byte X rows of the 256-column tile: the XOR only touches the low five bits of the 8-byte unit index, i.e. it
             // permutes units inside each 256-byte bank row exactly as for 256-byte rows)
 #pragma unroll
-            for (int t = 0; t < TC; ++t) bfr[t] = load<1>(Xk, BNW * 2, c0 + t * 16, lane);
+            for (int t = 0; t < TC; ++t) bfr[t] = (YMI_WGRAD_ABL & 4) ? bf16x8{} : load<1>(Xk, BNW * 2, c0 + t * 16, lane);
+            if (YMI_WGRAD_ABL & 4) {
+#pragma unroll
+                for (int t = 0; t < TR; ++t) asm volatile("" : "+v"(af[t]));
+#pragma unroll
+                for (int t = 0; t < TC; ++t) asm volatile("" : "+v"(bfr[t]));
+            }
 #pragma unroll
             for (int a = 0; a < TR; ++a)
 #pragma unroll
-                for (int b = 0; b < TC; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);  // operands swapped: see the epilogue
+                for (int b = 0; b < TC; ++b) {
+                    if (YMI_WGRAD_ABL & 2) { asm volatile("" :: "v"(bfr[b]), "v"(af[a])); continue; }
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);  // operands swapped: see the epilogue
+                }
             if (BIAS && bias) {  // (wave-uniform) column sums of dY: a row of ones against the dY fragments already in registers - TR more MFMAs
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 one8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // 1.0 in bfloat16
@@ -335,14 +350,17 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         for (int i = 0; i < NY; ++i) {
             const bool ok = y_cok && y_row[i] < left;
             const T* src = ok ? yg + y_off[i] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * NT + (wave * 64) % YT) * 16), 16, 0, 0);
+            if (!(YMI_WGRAD_ABL & 1) || mk < m_begin + (NS - 1) * WG_BK) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * NT + (wave * 64) % YT) * 16), 16, 0, 0);
+            else asm volatile("" :: "v"(src));
             y_off[i] += y_step;
         }
 #pragma unroll
         for (int i = 0; i < NX; ++i) {
             const bool ok = x_cok && x_row[i] < left && (unsigned)(x_hs[i] + dh) < (unsigned)a.H && (unsigned)(x_ws[i] + dw) < (unsigned)a.W;
             const T* src = ok ? xg + x_off[i] : zero;
-            __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * NT + wave * 64) * 16), 16, 0, 0);
+            if (!(YMI_WGRAD_ABL & 1) || mk < m_begin + (NS - 1) * WG_BK) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * NT + wave * 64) * 16), 16, 0, 0);
+            else asm volatile("" :: "v"(src));
+            if (YMI_WGRAD_ABL & 8) continue;
             // one K step on
             x_ws[i] += r_ * s_;
             x_hs[i] += q_ * s_;
@@ -418,12 +436,75 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
             if (co < a.CoutP) a.bias_slab[(int64_t)bz * a.CoutP + co] = accb[r][0];
         }
     }
+    if (std::is_same<T, bf16_t>::value && a.slab_bf16 && !(YMI_WGRAD_ABL & 16) && !YMI_WGRAD_DIRECT_SLAB) {
+        // bfloat16 slabs leave through LDS (round 5): written straight from the accumulators, a store instruction covers 16 rows x 32 bytes -
+        // sixteen partial lines - and those stores cost 8 % of the family's time (0.7 ms per step if nothing hid them: tools/probes/
+        // r5_wgrad_ablate.sh).  Each wave drops 32 rows x 64 columns of its tile into a private padded image and stores it back as whole
+        // 128-byte row segments, eight rows per instruction.  Same values, same rounding.
+        __syncthreads();  // the other waves may still read the last K step's stage
+        constexpr int SROW = 144;                 // padded row: 16 rows hit 16 distinct bank groups
+        constexpr int RP = TR < 2 ? TR : 2;       // 16-row tiles per pass
+        char* st = smem + wave * (RP * 16 * SROW);
+        bf16_t* slab = reinterpret_cast<bf16_t*>(a.slab) + slab_off;
+        const int srow = lane >> 3, sch = lane & 7;
+        const int col = j0 + wc * 64 + sch * 8;
+#pragma unroll
+        for (int r0 = 0; r0 < TR; r0 += RP) {
+#pragma unroll
+            for (int rr = 0; rr < RP; ++rr)
+#pragma unroll
+                for (int c = 0; c < TC; ++c) {
+                    const bf16x4 v = {(bf16_t)acc[r0 + rr][c][0], (bf16_t)acc[r0 + rr][c][1], (bf16_t)acc[r0 + rr][c][2], (bf16_t)acc[r0 + rr][c][3]};
+                    *reinterpret_cast<bf16x4*>(st + (rr * 16 + l15) * SROW + (c * 16 + 4 * l4) * 2) = v;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < RP * 2; ++k) {
+                const int row = k * 8 + srow;
+                const uint4 u = *reinterpret_cast<const uint4*>(st + row * SROW + sch * 16);
+                const int co = co0 + wr * (BM / WROWS) + r0 * 16 + row;
+                if (co < a.CoutP && col < a.NG) *reinterpret_cast<uint4*>(slab + (int64_t)co * a.NG + col) = u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else if (std::is_same<T, bf16_t>::value && !(YMI_WGRAD_ABL & 16) && !YMI_WGRAD_DIRECT_SLAB) {
+        // float32 slabs of the bf16 path (fewer than 16 splits): the same, 16 rows x 64 columns per pass, 256-byte row segments, four rows per instruction
+        __syncthreads();
+        constexpr int SROW = 272;
+        char* st = smem + wave * (16 * SROW);
+        float* slab = reinterpret_cast<float*>(a.slab) + slab_off;
+        const int srow = lane >> 4, sch = lane & 15;
+        const int col = j0 + wc * 64 + sch * 4;
+#pragma unroll
+        for (int r = 0; r < TR; ++r) {
+#pragma unroll
+            for (int c = 0; c < TC; ++c) *reinterpret_cast<f32x4*>(st + l15 * SROW + (c * 16 + 4 * l4) * 4) = acc[r][c];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int row = k * 4 + srow;
+                const f32x4 u = *reinterpret_cast<const f32x4*>(st + row * SROW + sch * 16);
+                const int co = co0 + wr * (BM / WROWS) + r * 16 + row;
+                if (co < a.CoutP && col < a.NG) *reinterpret_cast<f32x4*>(slab + (int64_t)co * a.NG + col) = u;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    } else
 #pragma unroll
     for (int r = 0; r < TR; ++r) {
         const int co = co0 + wr * (BM / WROWS) + r * 16 + l15;
 #pragma unroll
         for (int c = 0; c < TC; ++c) {
             const int col = j0 + wc * 64 + c * 16 + 4 * l4;
+            if (YMI_WGRAD_ABL & 16) { asm volatile("" :: "v"(acc[r][c])); continue; }
             if (co < a.CoutP && col < a.NG) {
                 const int64_t e = slab_off + (int64_t)co * a.NG + col;
                 if (std::is_same<T, bf16_t>::value && a.slab_bf16) {
