@@ -20,6 +20,7 @@ for l in a b; do
   if [ $l = a ]; then args=$aa; envs=$ea; else args=$ab; envs=$eb; fi
   [ -n "$envs" ] && export $envs
   rocprofv3 --kernel-trace --output-format csv -d $out/trace_$l -o p -- python3 $root/bench.py --no-cpu-baseline --no-forward --no-kernel-timing --sustained 0 --steps 6 --warmup 2 $args > /dev/null 2> $out/trace_$l.err
+  [ -n "$envs" ] && for kv in $envs; do unset ${kv%%=*}; done
   cp $(ls $out/trace_$l/*kernel_trace.csv $out/trace_$l/*/*kernel_trace.csv 2>/dev/null | head -1) $out/trace_$l.csv
   rm -rf $out/trace_$l
 done
