@@ -129,6 +129,9 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
     }
 }
 
+#ifndef YMI_IGEMM_ABL  // diagnostic builds (results wrong by design): bit 1 no LDS-DMA pieces inside the K loop, 2 no MFMAs, 4 no fragment reads,
+#define YMI_IGEMM_ABL 0  // 8 no global stores in the epilogue, 16 no epilogue at all
+#endif
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
     // one K step = CPR 16-byte chunks per row = CPR/4 16x16x32 MFMAs per tile pair.
@@ -152,6 +155,13 @@ template <> struct Mma<bf16_t> {
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
             const uint32_t coff = (uint32_t)(((4 * ks + l4) ^ sw) << 4);
+            if (YMI_IGEMM_ABL & 4) {
+#pragma unroll
+                for (int tn = 0; tn < TN; ++tn) wf[ks][tn] = bf16x8{};
+#pragma unroll
+                for (int tm = 0; tm < TM; ++tm) xf[ks][tm] = bf16x8{};
+                continue;
+            }
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
                 asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[ks][tn]) : "v"(bbase + coff), "n"(tn * 16 * ROWB));
@@ -173,7 +183,8 @@ template <> struct Mma<bf16_t> {
 #pragma unroll
             for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
-                for (int tm = 0; tm < TM; ++tm) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
+                for (int tm = 0; tm < TM; ++tm)
+                    if (!(YMI_IGEMM_ABL & 2)) acc[tn][tm] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][tn], xf[ks][tm], acc[tn][tm], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -420,7 +431,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x4 (&acc)[
                 const int m = m0 + row, ch = n0 + cc * EPC;
                 if (m < a.M && ch < a.Cout) {
                     const u32x4 val = *reinterpret_cast<const u32x4*>(Cimg + row * CROW + cc * 16);
-                    *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
+                    if (YMI_IGEMM_ABL & 8) asm volatile("" :: "v"(val));
+                    else *reinterpret_cast<u32x4*>(yg + out_offset(m) + ch) = val;
                 }
             }
         } else {  // fused inference convolutions (SiLU, then the shortcut), element-aligned addends, activation-gradient multiplier
@@ -776,9 +788,6 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
 #ifndef YMI_PP_PRIO
 #define YMI_PP_PRIO 0
 #endif
-#ifndef YMI_IGEMM_ABL  // diagnostic builds (results wrong by design): bit 1 no LDS-DMA pieces inside the K loop, 2 no MFMAs, 4 no fragment reads
-#define YMI_IGEMM_ABL 0
-#endif
         constexpr int NMEM = YMI_PP_ALLMEM ? NA + NB : NA;  // pieces issued in the memory phase (pieces are numbered A rows first)
         constexpr int NPC = NA + NB;       // pieces per wave and step
         constexpr int NM = (CPR / 4) * TN * TM;
@@ -881,7 +890,7 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             }
             YMI_STAMP(kt);  // 1: past the wait + barrier
             // every wave has passed the barrier => nobody still reads the buffer of step kt-1: refill it
-            if (kt + NS - 1 < nkt) issue((kt + NS - 1) % NS);
+            if (kt + NS - 1 < nkt && !(YMI_IGEMM_ABL & 1)) issue((kt + NS - 1) % NS);
             YMI_STAMP(kt);  // 2: pieces issued
             const char* As = smem + (kt % NS) * STAGE;
             Mma<T>::template step<TM, TN, CPR>(As, As + BM * ROWB, wm * TM * 16, wn * TN * 16, lane, acc);
@@ -899,6 +908,12 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
 #ifdef YMI_STAMPS
     igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all, stamp_on, wave_all, stamp_mt0);
 #else
+    if (YMI_IGEMM_ABL & 16) {
+#pragma unroll
+        for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm) asm volatile("" :: "v"(acc[tn][tm]));
+    } else
     igemm_epilogue<T, BM, BN, WM, WN, STATS, NT>(a, acc, smem, m0, n0, mb, wm, wn, lane, tid_all);
 #endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
