@@ -64,6 +64,7 @@ enum YmiOpt {
     OPT_IGEMM_TILE_BN,
     OPT_BN_TAIL,          // 1: BatchNorm backward's final pass inside the reduce kernel (last-arriver hand-off: measured slower,
                           //    profiles/r05_bn_tail_ab.txt); 0 (default): its own launch
+    OPT_WGRAD_PATCH,      // 1 (default): the weight gradient sums pixels in patch order with scalar addressing where the map tiles; 0: raster walk
     OPT_COUNT
 };
 int ymi_opt(int id);

@@ -47,7 +47,7 @@ struct OptEntry {
 };
 static OptEntry g_opts[OPT_COUNT] = {
     {"ew_ppt", 32}, {"ew_cap", 1024}, {"red_cap", 512}, {"xcd_shift", 0}, {"attn_tiled", 0}, {"wgrad_blocks", 1280}, {"wgrad_blocks128", 768},
-    {"igemm_tile_bm", 0}, {"igemm_tile_bn", 0}, {"bn_tail", 0},
+    {"igemm_tile_bm", 0}, {"igemm_tile_bn", 0}, {"bn_tail", 0}, {"wgrad_patch", 1},
 };
 static void opts_from_env() {
     for (int i = 0; i < OPT_COUNT; ++i) {

@@ -55,6 +55,8 @@ struct WgradArgs {
     int CoutP, Cin, NG;
     int pix_per_split;
     int nx, ny, splits, xcd_map;  // launch geometry (set by the launcher)
+    int pw_shift;                 // PATCH kernels: a K step is a (32 >> pw_shift) x (1 << pw_shift) patch of output pixels (see wgrad_kernel)
+    uint32_t x_bytes, y_bytes;    // ... and the operands as buffers (sizes in bytes, < 2^31)
     uint32_t wo_mul, wo_shr, ho_mul, ho_shr;  // n / Wo, n / Ho by multiply-high (wg_fast_div)
 };
 
@@ -73,12 +75,23 @@ constexpr int WG_BK = 32;    // pixels per K step (64 was measured 10-15 % slowe
 #ifndef YMI_WGRAD_ABL  // diagnostic builds (results wrong by design): bit 1 no LDS-DMA pieces inside the K loop, 2 no MFMAs, 4 no fragment reads, 8 no pixel walk, 16 no slab stores
 #define YMI_WGRAD_ABL 0
 #endif
+#ifndef YMI_WGRAD_NS  // LDS ring stages of the bf16 kernels
+#define YMI_WGRAD_NS 2
+#endif
 #ifndef YMI_WGRAD_DIRECT_SLAB  // 1: bfloat16 slabs stored straight from the accumulators (the form before round 5; A/B builds)
 #define YMI_WGRAD_DIRECT_SLAB 0
 #endif
 #ifndef YMI_WGRAD_WAVES
 #define YMI_WGRAD_WAVES 5  // waves per SIMD the register allocation must allow (the kernel is latency-bound: occupancy pays)
 #endif
+// `buffer_load_dwordx4 ... lds`: 16 bytes per lane from base + voff + soff into LDS (lane-linear behind `dst`), zeros for lanes whose offset is
+// outside [0, bytes).  The resource is rebuilt from (base, bytes) at every call - four scalar moves - because a local of the resource type in a
+// kernel TEMPLATE makes the host pass drop the instantiation's launch stub without a word (ROCm 7.2 clang): the type stays inside this function.
+__device__ __forceinline__ void wg_buffer_to_lds(const void* base, uint32_t bytes, lptr_t dst, uint32_t voff, uint32_t soff) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(__builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000), dst, 16, voff, soff, 0, 0);
+#endif
+}
 template <typename T> struct WFrag;
 // LDS bank swizzle for the transposed reads (bf16).  ds_read_b64_tr_b16 is serviced per 32-lane half: 2 groups x
 // (4 rows x 4 eight-byte units); the 8 rows of a half are {r0..r0+3, r0+8..r0+11}.  With 128-byte (dY) or 256-byte
@@ -94,54 +107,83 @@ template <int SW> __device__ __forceinline__ int wg_swz(int row) { return SW == 
 template <int BM> struct YSwz { static constexpr int SW = BM == 128 ? 1 : BM == 32 ? 2 : 0; };
 
 template <> struct WFrag<bf16_t> {
-    // fragment of 8 k-values (pixels 8g..8g+7) for column c0+i of a [pixel][col] LDS image with `rowb` bytes per row
+    // a fragment = 8 k-values (pixels 8g..8g+7) for column c0+i of a [pixel][col] LDS image with `rowb` bytes per row
+    // The reads are written as inline assembly (round 5).  Through the builtin the compiler sees LDS reads that may alias the LDS-DMA pieces
+    // issued a few instructions earlier and puts `s_waitcnt vmcnt(0)` in front of them: every K step then waited for the pieces of the NEXT
+    // step before it read its own fragments - the whole load latency exposed in every wave, every step (found in the ISA while building
+    // the patch walk; it had been there since round 1).  The ring's protocol (counted wait + barrier at the top of a step, pieces only into
+    // the stage nobody reads) is what orders the two; the compiler cannot know and must not add to it.
+    struct Addr { uint32_t lo, hi; };
     template <int SW>
-    static __device__ __forceinline__ bf16x8 load(const char* img, int rowb, int c0, int lane) {
+    static __device__ __forceinline__ Addr addr(const char* img, int rowb, int c0, int lane) {
         const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
         const int r_lo = 8 * g + q, r_hi = r_lo + 4;
         const int u = (c0 >> 2) + p;  // logical 8-byte unit of this lane's 4 columns
         const int u_lo = u ^ (wg_swz<SW>(r_lo) << 2);
         const int u_hi = u ^ (wg_swz<SW>(r_hi) << 2);
-        s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + r_lo * rowb + u_lo * 8));
-        s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(img + r_hi * rowb + u_hi * 8));
-        typedef __attribute__((ext_vector_type(8))) short s16x8;
-        s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        return __builtin_bit_cast(bf16x8, v);
+        return Addr{(uint32_t)(uintptr_t)(lptr_t)(img + r_lo * rowb + u_lo * 8), (uint32_t)(uintptr_t)(lptr_t)(img + r_hi * rowb + u_hi * 8)};
+    }
+    static __device__ __forceinline__ void read2(bf16x8& f, const Addr& ad) {  // two transposed 8-byte reads fill one 8-value fragment
+        typedef __attribute__((ext_vector_type(2))) uint32_t u2;
+        u2 lo, hi;
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(ad.lo));
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(ad.hi));
+        const u32x4 v = {lo[0], lo[1], hi[0], hi[1]};
+        f = __builtin_bit_cast(bf16x8, v);
     }
     template <int BM, int TR, int TC, int BNW = WG_BN, bool BIAS = false>
     static __device__ __forceinline__ void step(const char* Ys, const char* Xs, int r0, int c0, int lane, f32x4 (&acc)[TR][TC], bool bias, f32x4 (&accb)[BIAS ? TR : 1]) {
+        static_assert(WG_BK == 32, "one 32-deep sub-step");
+        bf16x8 af[TR], bfr[TC];
+        if (YMI_WGRAD_ABL & 4) {
 #pragma unroll
-        for (int ks = 0; ks < WG_BK / 32; ++ks) {  // pixel rows 32*ks .. 32*ks+31 (the swizzles use row bits 0..3 only)
-            const char* Yk = Ys + ks * 32 * BM * 2;
-            const char* Xk = Xs + ks * 32 * BNW * 2;
-            bf16x8 af[TR], bfr[TC];
+            for (int t = 0; t < TR; ++t) { af[t] = bf16x8{}; asm volatile("" : "+v"(af[t])); }
 #pragma unroll
-            for (int t = 0; t < TR; ++t) af[t] = (YMI_WGRAD_ABL & 4) ? bf16x8{} : load<YSwz<BM>::SW>(Yk, BM * 2, r0 + t * 16, lane);  // by the dY image's row width
+            for (int t = 0; t < TC; ++t) { bfr[t] = bf16x8{}; asm volatile("" : "+v"(bfr[t])); }
+        } else {
+            // addresses first (plain arithmetic), then every read of the step back to back: X fragments, then the dY fragments in the
+            // order the MFMA rows use them
+            Addr ay[TR], ax[TC];
+#pragma unroll
+            for (int t = 0; t < TR; ++t) ay[t] = addr<YSwz<BM>::SW>(Ys, BM * 2, r0 + t * 16, lane);  // by the dY image's row width
             // (512-byte X rows of the 256-column tile: the XOR only touches the low five bits of the 8-byte unit index, i.e. it
             // permutes units inside each 256-byte bank row exactly as for 256-byte rows)
 #pragma unroll
-            for (int t = 0; t < TC; ++t) bfr[t] = (YMI_WGRAD_ABL & 4) ? bf16x8{} : load<1>(Xk, BNW * 2, c0 + t * 16, lane);
-            if (YMI_WGRAD_ABL & 4) {
+            for (int t = 0; t < TC; ++t) ax[t] = addr<1>(Xs, BNW * 2, c0 + t * 16, lane);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int t = 0; t < TR; ++t) asm volatile("" : "+v"(af[t]));
+            for (int t = 0; t < TC; ++t) read2(bfr[t], ax[t]);
 #pragma unroll
-                for (int t = 0; t < TC; ++t) asm volatile("" : "+v"(bfr[t]));
+            for (int t = 0; t < TR; ++t) read2(af[t], ay[t]);
+        }
+#pragma unroll
+        for (int a = 0; a < TR; ++a) {
+            // row a needs the X fragments and dY fragment a: the 2 * (TR - 1 - a) younger reads may still be in flight
+            __builtin_amdgcn_sched_barrier(0);
+            if (!(YMI_WGRAD_ABL & 4)) {
+                if (a == 0) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * (TR - 1)) : "memory");
+                else if (a == 1) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TR > 2 ? 2 * (TR - 2) : 0) : "memory");
+                else if (a == 2) asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(TR > 3 ? 2 * (TR - 3) : 0) : "memory");
+                else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            }
+            asm volatile("" : "+v"(af[a]));
+            if (a == 0) {
+#pragma unroll
+                for (int b = 0; b < TC; ++b) asm volatile("" : "+v"(bfr[b]));
             }
 #pragma unroll
-            for (int a = 0; a < TR; ++a)
-#pragma unroll
-                for (int b = 0; b < TC; ++b) {
-                    if (YMI_WGRAD_ABL & 2) { asm volatile("" :: "v"(bfr[b]), "v"(af[a])); continue; }
-                    acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);  // operands swapped: see the epilogue
-                }
-            if (BIAS && bias) {  // (wave-uniform) column sums of dY: a row of ones against the dY fragments already in registers - TR more MFMAs
+            for (int b = 0; b < TC; ++b) {
+                if (YMI_WGRAD_ABL & 2) { asm volatile("" :: "v"(bfr[b]), "v"(af[a])); continue; }
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[b], af[a], acc[a][b], 0, 0, 0);  // operands swapped: see the epilogue
+            }
+            if (BIAS && bias) {  // (wave-uniform) column sums of dY: a row of ones against the dY fragment already in registers - one more MFMA per row
                 typedef __attribute__((ext_vector_type(8))) short s16x8;
                 const s16x8 one8 = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};  // 1.0 in bfloat16
                 const bf16x8 ones = __builtin_bit_cast(bf16x8, one8);
-#pragma unroll
-                for (int a = 0; a < (BIAS ? TR : 1); ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], accb[a], 0, 0, 0);
+                if constexpr (BIAS) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, af[a], accb[a], 0, 0, 0);
             }
         }
+        __builtin_amdgcn_sched_barrier(0);
     }
 };
 template <> struct WFrag<float> {
@@ -239,7 +281,14 @@ __device__ __forceinline__ void wgrad_rider_final(const YmiBnRider& r, int w, ch
     }
 }
 
-template <typename T, int NS, int BM, bool BIAS = false>
+// PATCH (round 5): the K axis runs over the output pixels in PATCH order instead of raster order - step k is a ph x pw patch (ph * pw = 32, pw a power
+// of two dividing Wo, ph dividing Ho) whose origin (n, ho0, wo0) is SCALAR state.  A lane's row of the step is a fixed (pr, pc) inside the patch, so its
+// source offset is a per-thread constant plus a scalar: the pieces become `buffer_load_dwordx4 ... lds` with the constant in the vector offset and the
+// patch origin in the scalar offset, padding taps are lanes whose vector offset is pushed out of range (the buffer unit writes zeros to LDS for them:
+// tools/probes/bar/buffer_lds_probe.hip), and the per-lane (ho, wo) walk with its wraps - as many issue slots as the MFMAs (tools/probes/
+// r5_wgrad_ablate.sh) - is five vector instructions per X piece and none per dY piece.  Any fixed order of the pixel sum is as good as raster order;
+// maps that do not tile into such patches (20 x 20) keep the raster walk.
+template <typename T, int NS, int BM, bool BIAS = false, bool PATCH = false>
 __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_kernel(WgradArgs a, YmiBnRider rider) {
     constexpr int BNW = WG_BN, NT = 256;
     constexpr int CH = ElemTraits<T>::CH;
@@ -342,15 +391,76 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         y_off[i] = (uint32_t)((m_begin + y_row[i]) * ldy32 + co0 + ycc * CH);
     }
     const uint32_t y_step = (uint32_t)(WG_BK * ldy32);
+    // ---- PATCH: per-thread constants and the scalar patch walk
+    constexpr uint32_t OOR = 0x80000000u;  // a vector offset beyond any buffer of < 2^31 bytes (vector + scalar offset stays below 2^32)
+    const int pw = 1 << a.pw_shift, ph = WG_BK >> a.pw_shift;
+    const uint32_t xbias = PATCH ? (uint32_t)((a.W + 1) * ldx32 * ES) : 0u;  // keeps the (dh, dw) = (-1, -1) offsets non-negative
+    const char* xbase = reinterpret_cast<const char*>(xg) - xbias;
+    uint32_t pvx[NX], pvy[NY];
+    int pch[NX], pcw[NX];
+    int p_wo = 0, p_ho = 0;            // scalar: the next patch's origin
+    uint32_t p_sx = 0, p_sy = 0;       // scalar byte offsets of that origin in X (tap (0, 0), channel 0) and dY
+    if constexpr (PATCH) {
+#pragma unroll
+        for (int i = 0; i < NX; ++i) {
+            const int row = tid / XCW + i * (NT / XCW);
+            const int pr = row >> a.pw_shift, pc = row & (pw - 1);
+            pch[i] = pr * s_ + dh;
+            pcw[i] = pc * s_ + dw;
+            pvx[i] = x_cok ? (uint32_t)(((pch[i] * a.W + pcw[i]) * ldx32 + ci) * ES) + xbias : OOR;
+        }
+#pragma unroll
+        for (int i = 0; i < NY; ++i) {
+            const int row = ytid / YCW + i * (NT / YCW);
+            const int pr = row >> a.pw_shift, pc = row & (pw - 1);
+            pvy[i] = y_cok ? (uint32_t)(((pr * a.Wo + pc) * ldy32 + co0 + ycc * CH) * ES) : OOR;
+        }
+        const int pidx = __builtin_amdgcn_readfirstlane(m_begin / WG_BK);  // first patch of this split
+        const int npw = a.Wo >> a.pw_shift, nph = a.Ho / ph;
+        const int t = pidx / npw, wp = pidx - t * npw;
+        const int n = t / nph, hp = t - n * nph;
+        p_wo = wp * pw;
+        p_ho = hp * ph;
+        p_sx = (uint32_t)(((n * a.H + p_ho * s_) * a.W + p_wo * s_) * ldx32 * ES);
+        p_sy = (uint32_t)(((n * a.Ho + p_ho) * a.Wo + p_wo) * ldy32 * ES);
+    }
     auto issue = [&](int s, int mk) {
         char* Ys = smem + s * STAGE;
         char* Xs = Ys + YBYTES;
+        const bool live = !(YMI_WGRAD_ABL & 1) || mk < m_begin + (NS - 1) * WG_BK;
+        if constexpr (PATCH) {
+            const uint32_t sx = __builtin_amdgcn_readfirstlane(p_sx), sy = __builtin_amdgcn_readfirstlane(p_sy);  // (scalar by construction; said so)
+#pragma unroll
+            for (int i = 0; i < NY; ++i)
+                if (live) wg_buffer_to_lds(yg, a.y_bytes, (lptr_t)(Ys + (i * NT + (wave * 64) % YT) * 16), pvy[i], sy);
+            const int hs0 = __builtin_amdgcn_readfirstlane(p_ho * s_), ws0 = __builtin_amdgcn_readfirstlane(p_wo * s_);
+#pragma unroll
+            for (int i = 0; i < NX; ++i) {
+                const bool ok = (unsigned)(hs0 + pch[i]) < (unsigned)a.H && (unsigned)(ws0 + pcw[i]) < (unsigned)a.W;
+                if (live) wg_buffer_to_lds(xbase, a.x_bytes + xbias, (lptr_t)(Xs + (i * NT + wave * 64) * 16), ok ? pvx[i] : OOR, sx);
+            }
+            // one patch on (scalar)
+            p_wo += pw;
+            p_sx += (uint32_t)(pw * s_ * ldx32 * ES);
+            p_sy += (uint32_t)(pw * ldy32 * ES);
+            if (p_wo == a.Wo) {
+                p_wo = 0;
+                p_ho += ph;
+                p_sx += (uint32_t)((ph * s_ * a.W - a.Wo * s_) * ldx32 * ES);
+                p_sy += (uint32_t)((ph * a.Wo - a.Wo) * ldy32 * ES);
+                if (p_ho == a.Ho) {
+                    p_ho = 0;
+                    p_sx += (uint32_t)((a.H * a.W - a.Ho * s_ * a.W) * ldx32 * ES);
+                }
+            }
+            return;
+        }
         const int left = m_end - mk;  // scalar: rows below it are inside this split
 #pragma unroll
         for (int i = 0; i < NY; ++i) {
             const bool ok = y_cok && y_row[i] < left;
             const T* src = ok ? yg + y_off[i] : zero;
-            if (!(YMI_WGRAD_ABL & 1) || mk < m_begin + (NS - 1) * WG_BK) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * NT + (wave * 64) % YT) * 16), 16, 0, 0);
+            if (live) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Ys + (i * NT + (wave * 64) % YT) * 16), 16, 0, 0);
             else asm volatile("" :: "v"(src));
             y_off[i] += y_step;
         }
@@ -358,7 +468,7 @@ __global__ __launch_bounds__(256, (BM == 128 ? 3 : YMI_WGRAD_WAVES)) void wgrad_
         for (int i = 0; i < NX; ++i) {
             const bool ok = x_cok && x_row[i] < left && (unsigned)(x_hs[i] + dh) < (unsigned)a.H && (unsigned)(x_ws[i] + dw) < (unsigned)a.W;
             const T* src = ok ? xg + x_off[i] : zero;
-            if (!(YMI_WGRAD_ABL & 1) || mk < m_begin + (NS - 1) * WG_BK) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * NT + wave * 64) * 16), 16, 0, 0);
+            if (live) __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(Xs + (i * NT + wave * 64) * 16), 16, 0, 0);
             else asm volatile("" :: "v"(src));
             if (YMI_WGRAD_ABL & 8) continue;
             // one K step on
@@ -734,19 +844,24 @@ static void wgrad_launch(const WgradLaunch& h, const YmiBnRider* rider) {
     if (ymi_prof_enabled()) prof = ymi_prof_start(s, 1, h.flop, h.bytes, h.bf16 ? 2500.0 : 157.3);
 #define YMI_WG_LAUNCH(T, BMV, LDS)                                                                                   \
     do {                                                                                                            \
-        if (a.bias_slab) hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, true>), grid, dim3(256), (LDS), s, a, r);       \
-        else hipLaunchKernelGGL((wgrad_kernel<T, 2, BMV, false>), grid, dim3(256), (LDS), s, a, r);                  \
+        if (a.pw_shift >= 0) {                                                                                      \
+            if (a.bias_slab) hipLaunchKernelGGL((wgrad_kernel<T, YMI_WGRAD_NS, BMV, true, true>), grid, dim3(256), (LDS), s, a, r);  \
+            else hipLaunchKernelGGL((wgrad_kernel<T, YMI_WGRAD_NS, BMV, false, true>), grid, dim3(256), (LDS), s, a, r);        \
+        } else if (a.bias_slab) hipLaunchKernelGGL((wgrad_kernel<T, YMI_WGRAD_NS, BMV, true>), grid, dim3(256), (LDS), s, a, r);  \
+        else hipLaunchKernelGGL((wgrad_kernel<T, YMI_WGRAD_NS, BMV, false>), grid, dim3(256), (LDS), s, a, r);                  \
     } while (0)
     if (h.bf16) {
         // two LDS stages (deeper rings measured equal: same bytes in flight per CU)
-        if (h.bm == 128) YMI_WG_LAUNCH(bf16_t, 128, (size_t)2 * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS);
-        else if (h.bm == 32) YMI_WG_LAUNCH(bf16_t, 32, (size_t)2 * (WG_BK * (32 + WG_BN) * 2) + WG_STAMP_LDS);
-        else YMI_WG_LAUNCH(bf16_t, 64, (size_t)2 * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS);
+        if (h.bm == 128) YMI_WG_LAUNCH(bf16_t, 128, (size_t)YMI_WGRAD_NS * (WG_BK * (128 + WG_BN) * 2) + WG_STAMP_LDS);
+        else if (h.bm == 32) YMI_WG_LAUNCH(bf16_t, 32, (size_t)YMI_WGRAD_NS * (WG_BK * (32 + WG_BN) * 2) + WG_STAMP_LDS);
+        else YMI_WG_LAUNCH(bf16_t, 64, (size_t)YMI_WGRAD_NS * (WG_BK * (64 + WG_BN) * 2) + WG_STAMP_LDS);
     } else {
         const size_t lds = 2 * (size_t)(WG_BK * (WG_BM + WG_BN) * 4);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel<float, 2, 64, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        YMI_WG_LAUNCH(float, 64, lds);
+        // (parity mode keeps the raster walk: pw_shift is -1 for float32 operands)
+        if (a.bias_slab) hipLaunchKernelGGL((wgrad_kernel<float, 2, 64, true>), grid, dim3(256), lds, s, a, r);
+        else hipLaunchKernelGGL((wgrad_kernel<float, 2, 64, false>), grid, dim3(256), lds, s, a, r);
     }
 #undef YMI_WG_LAUNCH
     ymi_prof_stop(s, prof);
@@ -869,6 +984,23 @@ static int wgrad_impl(const ymi_tensor* x, const ymi_tensor* dy, int64_t cout_re
     wg_find_divisor(a.Wo, &a.wo_mul, &a.wo_shr);
     wg_find_divisor(a.Ho, &a.ho_mul, &a.ho_shr);
     a.nx = (int)((ng + bn - 1) / bn); a.ny = (int)((dy->c + bm - 1) / bm); a.splits = p.splits;
+    // patch order of the pixel sum (see wgrad_kernel): the widest power-of-two patch width that divides Wo with a height that divides Ho
+    a.pw_shift = -1;
+    {
+        const int64_t xb = ymi_pixels(x) * x->ld * ymi_esize(x->dtype), yb = ymi_pixels(dy) * dy->ld * ymi_esize(dy->dtype);
+        const int64_t margin = (x->w + 2) * x->ld * (int64_t)ymi_esize(x->dtype);
+        if (bf16 && ymi_opt(OPT_WGRAD_PATCH) && xb + margin < (1ll << 31) && yb < (1ll << 31) && mpix % WG_BK == 0) {
+            for (int sh = 5; sh >= 0; --sh) {
+                const int pw = 1 << sh, ph = WG_BK >> sh;
+                if (dy->w % pw == 0 && dy->h % ph == 0) {
+                    a.pw_shift = sh;
+                    break;
+                }
+            }
+            a.x_bytes = (uint32_t)xb;
+            a.y_bytes = (uint32_t)yb;
+        }
+    }
     a.xcd_map = p.splits >= 8 ? 1 : 0;  // (all tiles of a pixel split on one XCD: 275 -> 105 MB of HBM reads per launch, round 1)
     dim3 grid((unsigned)a.nx, (unsigned)a.ny, (unsigned)p.splits);
     if (a.xcd_map) grid = dim3((unsigned)(8 * ((p.splits + 7) / 8) * a.nx * a.ny), 1, 1);
