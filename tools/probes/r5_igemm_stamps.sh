@@ -13,5 +13,5 @@ if [ "$1" = build ]; then
 fi
 for n in ${ABLS:-0 7}; do
   echo "== stamps, igemm ablation mask $n"
-  YMI_LIB=$root/improving_yolov8_cbam_swinblock_amd/libyolo_ist$n.so python3 $root/tools/conv_bench.py --ops fwd,dgrad --iters 10 --stamps --only "${ONLY:-det.cv3[0]}" 2>&1
+  YMI_LIB=$root/improving_yolov8_cbam_swinblock_amd/libyolo_ist$n.so python3 $root/tools/conv_bench.py --ops ${OPS:-fwd,dgrad} --iters 10 --stamps --only "${ONLY:-det.cv3[0]}" 2>&1
 done
