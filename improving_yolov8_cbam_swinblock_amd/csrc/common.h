@@ -53,8 +53,8 @@ static inline bool ymi_same_shape(const ymi_tensor* a, const ymi_tensor* b) {
 // sizes for in-step sweeps, forced code paths for tests.  Each starts at its default, or at the value of the environment variable
 // YMI_<NAME> when the process starts with one (tools/*.sh sweeps); production code never sets any.
 enum YmiOpt {
-    OPT_EW_PPT,           // streaming BatchNorm passes: pixels per thread aimed for (32)
-    OPT_EW_CAP,           // ... and their workgroup cap (1024)
+    OPT_EW_PPT,           // streaming BatchNorm passes: pixels per thread aimed for (64)
+    OPT_EW_CAP,           // ... and their workgroup cap (512)
     OPT_RED_CAP,          // BatchNorm backward reduce: workgroup cap (512)
     OPT_XCD_SHIFT,        // streaming passes work on XCD (x + k) % 8's pixels: the anti-affine arrangement (0)
     OPT_ATTN_TILED,       // 1: tiled window attention for every window size (tests) (0)

@@ -130,7 +130,7 @@ template <int I, int N, class F> __device__ __forceinline__ void static_for(F&& 
 }
 
 #ifndef YMI_IGEMM_ABL  // diagnostic builds (results wrong by design): bit 1 no LDS-DMA pieces inside the K loop, 2 no MFMAs, 4 no fragment reads,
-#define YMI_IGEMM_ABL 0  // 8 no global stores in the epilogue, 16 no epilogue at all
+#define YMI_IGEMM_ABL 0  // 8 no global stores in the epilogue, 16 no epilogue at all, 32 A pieces of one tap in three only
 #endif
 template <typename T> struct Mma;
 template <> struct Mma<bf16_t> {
@@ -796,6 +796,9 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
             char* Ad = smem + s * STAGE;
             char* Bd = Ad + BM * ROWB;
             if (YMI_IGEMM_ABL & 1) return;
+            if constexpr (p < NA) {
+                if ((YMI_IGEMM_ABL & 32) && (tap_s % 3) != 1) return;  // emulates an input tile shared by the three taps of a kernel row (upper bound)
+            }
             if constexpr (p < NA) __builtin_amdgcn_global_load_lds((gptr_t)a_ptr[p], (lptr_t)(Ad + (p * LT + wave * 64) * 16), 16, 0, 0);
             else __builtin_amdgcn_global_load_lds((gptr_t)b_ptr[p - NA], (lptr_t)(Bd + ((p - NA) * LT + wave * 64) * 16), 16, 0, 0);
         };

@@ -40,13 +40,15 @@ const void* ymi_zero_page() {
 // Grid sizing of the streaming BatchNorm passes (ew_ppt / ew_cap), swept INSIDE the training step in round 4
 // (profiles/r04_ew_grid_sweep.txt; the round-1 values 8 / 2048 came from isolated launches): one resident round of four 256-thread
 // workgroups per CU, each thread walking up to 32 pixels, is 0.2 ms/step faster than eight per CU - fewer, longer workgroups amortise
-// the coefficient loads and the launch ramp, and the half-empty SIMDs do not matter to passes that wait on HBM.
+// the coefficient loads and the launch ramp, and the half-empty SIMDs do not matter to passes that wait on HBM.  Round 5, swept again in the
+// step after the finalize launches had moved into these passes' prologues (every thread now reads the statistics' replicas first): two
+// workgroups per CU, up to 64 pixels per thread: 11.641 -> 11.607 ms/step (profiles/r05_ew_grid_sweep.txt).
 struct OptEntry {
     const char* name;
     int value;
 };
 static OptEntry g_opts[OPT_COUNT] = {
-    {"ew_ppt", 32}, {"ew_cap", 1024}, {"red_cap", 512}, {"xcd_shift", 0}, {"attn_tiled", 0}, {"wgrad_blocks", 1280}, {"wgrad_blocks128", 768},
+    {"ew_ppt", 64}, {"ew_cap", 512}, {"red_cap", 512}, {"xcd_shift", 0}, {"attn_tiled", 0}, {"wgrad_blocks", 1280}, {"wgrad_blocks128", 768},
     {"igemm_tile_bm", 0}, {"igemm_tile_bn", 0}, {"bn_tail", 0}, {"wgrad_patch", 1},
 };
 static void opts_from_env() {
