@@ -759,7 +759,14 @@ __global__ __launch_bounds__(NTHR) void igemm_kernel(IgemmMulti P) {
         const int half = wave_all >> 2;  // 0: rows 0..BM/2-1 (starts first), 1: the other rows, half a step behind
         bf16x8 wf[CPR / 4][TN], xf[CPR / 4][TM];
 #ifdef YMI_PP_STAGGER  // diagnostic: the workgroup in the upper wave slots of its SIMDs starts YMI_PP_STAGGER * 64 cycles late
-        if (__builtin_amdgcn_s_getreg(4 | (3 << 11)) & 2) __builtin_amdgcn_s_sleep(YMI_PP_STAGGER);
+        if (__builtin_amdgcn_s_getreg(4 | (3 << 11)) & 2) {
+#ifdef YMI_PP_STAGGER_REP  // ... times 8,128 cycles: offsets of a fraction of a workgroup's lifetime (epilogue against K loop)
+#pragma unroll 1
+            for (int q = 0; q < YMI_PP_STAGGER_REP; ++q) __builtin_amdgcn_s_sleep(127);
+#else
+            __builtin_amdgcn_s_sleep(YMI_PP_STAGGER);
+#endif
+        }
 #endif
         issue(0);
         if (nkt > 1) issue(1);
