@@ -500,6 +500,9 @@ struct BnFin {
     double inv_scale;  // 2^-shift of the fixed-point sums (common.h: ymi_stat_fixed_point_shift)
     float momentum, eps;
 };
+#ifndef YMI_EW_U  // pixels a thread of the affine pass keeps in flight per trip
+#define YMI_EW_U 4
+#endif
 template <typename T, int ACT, bool FIN = false>
 __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const float* __restrict__ scale, const float* __restrict__ shift,
                                                                     TV res, TV o, int groups, int64_t Pall, int64_t span, BnFin fin = BnFin{}) {
@@ -572,34 +575,35 @@ __global__ __launch_bounds__(256) void scale_shift_act_fixed_kernel(TV x, const 
     // 4 pixels per trip: the loads of all four are in flight before the first use, and the NEXT trip's (raw) loads are issued before this
     // trip's arithmetic (as in the BatchNorm backward passes, csrc/reduce_bwd.hip)
     typedef typename Raw4<T>::type R4;
-    R4 rv[4], rres[4];
-    bool have = p + 3 * step < P;
+    constexpr int U = YMI_EW_U;  // pixels per trip
+    R4 rv[U], rres[U];
+    bool have = p + (U - 1) * step < P;
     if (have) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             rv[u] = *reinterpret_cast<const R4*>(xp + (p + u * step) * x.ld + g * 4);
             if (rp) rres[u] = *reinterpret_cast<const R4*>(rp + (p + u * step) * res.ld + g * 4);
         }
     }
     while (have) {
-        float v[4][4], rr[4][4] = {};
+        float v[U][4], rr[U][4] = {};
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < U; ++u) {
             Raw4<T>::to_f32(rv[u], v[u]);
             if (rp) Raw4<T>::to_f32(rres[u], rr[u]);
         }
         const int64_t pc = p;
-        p += 4 * step;
-        have = p + 3 * step < P;
+        p += U * step;
+        have = p + (U - 1) * step < P;
         if (have) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 rv[u] = *reinterpret_cast<const R4*>(xp + (p + u * step) * x.ld + g * 4);
                 if (rp) rres[u] = *reinterpret_cast<const R4*>(rp + (p + u * step) * res.ld + g * 4);
             }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) one(v[u], rr[u], pc + u * step);
+        for (int u = 0; u < U; ++u) one(v[u], rr[u], pc + u * step);
     }
     for (; p < P; p += step) {
         float v[4], rr[4] = {0.f, 0.f, 0.f, 0.f};

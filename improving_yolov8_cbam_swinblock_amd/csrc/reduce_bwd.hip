@@ -61,6 +61,12 @@ struct ReduceTail {
     float* out1;
     BnCoefArgs bn;
 };
+#ifndef YMI_RED_U  // pixels a thread of the reduce pass keeps in flight per trip
+#define YMI_RED_U 4
+#endif
+#ifndef YMI_APPLY_U
+#define YMI_APPLY_U 4
+#endif
 template <typename T, int FN, int ACT>
 __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, int TG, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    const float* __restrict__ mean, const float* __restrict__ inv, float* __restrict__ part, GammaBeta2 g2, ReduceTail tail) {
@@ -118,34 +124,35 @@ __global__ void chan_reduce_kernel(RV a, RV b, int64_t P, int64_t span, int C, i
         // (raw, unconverted: 2 VGPRs each in bf16) before this trip's arithmetic, so a workgroup with several trips does not pay one
         // full memory round trip per trip (4 waves per SIMD are not enough to hide it: the arithmetic of a trip is as long as its loads)
         typedef typename Raw4<T>::type R4;
-        R4 ra[4], rb[4];
-        bool have = p + 3 * (int64_t)rows < p1;
+        constexpr int U = YMI_RED_U;  // pixels per trip
+        R4 ra[U], rb[U];
+        bool have = p + (U - 1) * (int64_t)rows < p1;
         if (have) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 ra[u] = *reinterpret_cast<const R4*>(ap + (p + u * (int64_t)rows) * a.ld + tx * 4);
                 if (FN != 0) rb[u] = *reinterpret_cast<const R4*>(bp + (p + u * (int64_t)rows) * b.ld + tx * 4);
             }
         }
         while (have) {
-            float va[4][4], vb[4][4];
+            float va[U][4], vb[U][4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < U; ++u) {
                 Raw4<T>::to_f32(ra[u], va[u]);
                 if (FN != 0) Raw4<T>::to_f32(rb[u], vb[u]);
             }
             const int64_t pc = p;
-            p += 4 * (int64_t)rows;
-            have = p + 3 * (int64_t)rows < p1;
+            p += U * (int64_t)rows;
+            have = p + (U - 1) * (int64_t)rows < p1;
             if (have) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
+                for (int u = 0; u < U; ++u) {
                     ra[u] = *reinterpret_cast<const R4*>(ap + (p + u * (int64_t)rows) * a.ld + tx * 4);
                     if (FN != 0) rb[u] = *reinterpret_cast<const R4*>(bp + (p + u * (int64_t)rows) * b.ld + tx * 4);
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) accum(va[u], vb[u], pc + u * (int64_t)rows);
+            for (int u = 0; u < U; ++u) accum(va[u], vb[u], pc + u * (int64_t)rows);
         }
         for (; p < p1; p += rows) {
             float va[4], vb[4];
@@ -440,7 +447,7 @@ __global__ __launch_bounds__(256) void bn_act_bwd_apply_kernel(RV dout, RV raw, 
             }
             Pack<T, G>::store(op + p * draw.ld + g * G, o);
         };
-        constexpr int U = G == 8 ? 2 : 4;  // pixels per trip: 2*U independent loads in flight per lane
+        constexpr int U = G == 8 ? 2 : YMI_APPLY_U;  // pixels per trip: 2*U independent loads in flight per lane
         // the pixels of this workgroup's XCD (common.h, XCD ownership of the pixel axis; the grid is a multiple of 8)
         const XcdRange xr = xcd_range(Pall, span);
         P = xr.hi;
