@@ -5,6 +5,7 @@
 #   kernel_categories.txt       per-family ms/step of the same
 #   bench_under_rocprof.json    the bench line printed by that profiled run
 #   fwd_kernel_stats.csv / fwd_kernel_categories.txt   the same for `bench.py --forward-only` (the train-mode forward alone)
+#   per_launch_bounds.txt       every GEMM launch of one eager step against its own roofline bound (tools/per_launch_bounds.py)
 #   pmc_traffic.json            HBM bytes per launch of the GEMM families: two separate --pmc passes (FETCH_SIZE, WRITE_SIZE), with the
 #                               workload they were taken on; also copied to profiles/<TAG>_pmc_traffic.json ON THE BOX for the second bench run
 #   (second argument `cfg5`) config 5, yolov8m-cbam-swin384 at bs 16, 1280x1280:
@@ -38,6 +39,10 @@ if [ "$2" != "cfg5only" ]; then
   mv $out/bench_kernel_stats.csv $out/kernel_stats.csv; mv $out/bench_kernel_categories.txt $out/kernel_categories.txt
   stats fwd 32 --forward-only --steps 27
   traffic pmc_traffic.json "yolov8s.yaml bs32 640" --no-cpu-baseline --no-forward --sustained 0 --steps 3 --warmup 1
+  # every GEMM launch against its own bound (HIP-event brackets of 4 eager steps; the last one is listed)
+  rm -f $out/prof_dump.txt
+  YMI_PROF_DUMP=$out/prof_dump.txt python3 $root/bench.py --no-cpu-baseline --no-forward --sustained 0 --graph 0 --steps 4 --warmup 2 > /dev/null 2> $out/prof_dump.err
+  python3 $root/tools/per_launch_bounds.py $out/prof_dump.txt 4 --list > $out/per_launch_bounds.txt || true
   # the default line, now that the PMC passes of THIS kernel revision exist (bench.py reports `traffic` only from a matching file)
   python3 $root/bench.py > $out/bench.json 2> $out/bench.err
   echo "bench done"
